@@ -1,0 +1,273 @@
+"""ctypes front-end of the CPU ORACLE (oracle/gsf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from gps_optimize_slam_amd/ (the product).
+
+Each wrapper mirrors one reference function of EKFGPSSLAM.py (file:line in the
+C source) with NumPy float64 C-order arrays in and out.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgsf_oracle.so")
+
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+# CONFIG defaults of the reference (EKFGPSSLAM.py:22-71)
+DEFAULT_CONFIG = {
+    "ekf": {
+        "initial_cov_diag": [0.1, 0.1, 0.1, 0.01, 0.01, 0.01, 0.01],
+        "process_noise_diag": [0.1, 0.1, 0.7, 0.01, 0.01, 0.01, 0.01],
+        "meas_noise_diag": [0.2, 0.2, 0.2],
+        "transition_steps": 10,
+    },
+    "sim3_ransac": {"min_samples": 4, "residual_threshold": 4.0, "max_trials": 1000,
+                    "min_inliers_needed": 4, "max_initial_duration": 180.0},
+    "time_alignment": {"max_samples_for_corr": 500, "max_gps_gap_threshold": 5.0},
+    "rts_decision": {"sharp_turn_yaw_rate_threshold_deg_per_sec": 45.0,
+                     "default_ekf_transition_steps_on_sharp_turn": 0},
+}
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("P0", C.c_double * 7), ("Qps", C.c_double * 7), ("Rm", C.c_double * 3),
+                ("transition_steps", C.c_int32), ("yaw_rate_thr_deg", C.c_double),
+                ("sharp_turn_steps", C.c_int32)]
+
+    @classmethod
+    def from_dict(cls, cfg=None):
+        cfg = cfg or DEFAULT_CONFIG
+        e, r = cfg["ekf"], cfg["rts_decision"]
+        c = cls()
+        c.P0[:] = e["initial_cov_diag"]
+        c.Qps[:] = e["process_noise_diag"]
+        c.Rm[:] = e["meas_noise_diag"]
+        c.transition_steps = int(e.get("transition_steps", 10))
+        c.yaw_rate_thr_deg = float(r["sharp_turn_yaw_rate_threshold_deg_per_sec"])
+        c.sharp_turn_steps = int(r["default_ekf_transition_steps_on_sharp_turn"])
+        return c
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "gsf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgsf_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_config_size.restype = C.c_int
+        assert L.orc_config_size() == C.sizeof(OrcConfig), "orc_config layout mismatch"
+        L.orc_relative_pose.restype = C.c_int
+        L.orc_relative_pose.argtypes = [f64p] * 6
+        L.orc_quaternion_nlerp.restype = None
+        L.orc_quaternion_nlerp.argtypes = [f64p, f64p, C.c_double, f64p]
+        L.orc_utm_zone.restype = C.c_int
+        L.orc_utm_zone.argtypes = [f64p, f64p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_utm_forward.restype = None
+        L.orc_utm_forward.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+        L.orc_utm_inverse.restype = None
+        L.orc_utm_inverse.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+        L.orc_umeyama.restype = C.c_int
+        L.orc_umeyama.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.POINTER(C.c_double)]
+        L.orc_sim3_ransac.restype = C.c_int
+        L.orc_sim3_ransac.argtypes = [f64p, f64p, C.c_int64, i32p, C.c_int, C.c_int, C.c_double, C.c_int,
+                                      f64p, f64p, C.POINTER(C.c_double), u8p, C.POINTER(C.c_int64)]
+        L.orc_transform_trajectory.restype = C.c_int
+        L.orc_transform_trajectory.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.c_double, f64p, f64p]
+        L.orc_ekf_process_step.restype = None
+        L.orc_ekf_process_step.argtypes = [C.POINTER(OrcConfig), f64p, f64p, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_double), C.c_int, f64p, f64p, f64p, C.c_int, C.c_int,
+                                           C.c_double, C.c_int, f64p, f64p]
+        L.orc_rts_segment.restype = None
+        L.orc_rts_segment.argtypes = [f64p, f64p, f64p, f64p, C.c_int64, f64p, f64p]
+        L.orc_is_sharp_turn.restype = C.c_int
+        L.orc_is_sharp_turn.argtypes = [f64p, f64p, C.c_int64, C.c_double, C.POINTER(C.c_double)]
+        L.orc_apply_ekf_correction.restype = C.c_int
+        L.orc_apply_ekf_correction.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, f64p, f64p,
+                                               C.POINTER(OrcConfig), f64p, f64p]
+        L.orc_fuse_batch.restype = None
+        L.orc_fuse_batch.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, C.c_int64, f64p, f64p,
+                                     C.POINTER(OrcConfig), f64p, f64p, i32p]
+        L.orc_estimate_time_offset.restype = C.c_double
+        L.orc_estimate_time_offset.argtypes = [f64p, C.c_int64, f64p, C.c_int64, C.c_int]
+        L.orc_dynamic_time_alignment.restype = None
+        L.orc_dynamic_time_alignment.argtypes = [f64p, C.c_int64, f64p, f64p, C.c_int64, C.c_int, C.c_double,
+                                                 f64p, u8p]
+        _lib = L
+    return _lib
+
+
+def _a(x, shape=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+# ---- EKFGPSSLAM.py:77-105 --------------------------------------------------
+def calculate_relative_pose(p1, q1, p2, q2):
+    dp, dq = np.empty(3), np.empty(4)
+    lib().orc_relative_pose(_a(p1), _a(q1), _a(p2), _a(q2), dp, dq)
+    return dp, dq
+
+
+def quaternion_nlerp(q1, q2, w):
+    out = np.empty(4)
+    lib().orc_quaternion_nlerp(_a(q1), _a(q2), float(w), out)
+    return out
+
+
+# ---- EKFGPSSLAM.py:127-134, :266-271, :291-296 ------------------------------
+def auto_utm_projection(lons, lats):
+    lons, lats = _a(lons).ravel(), _a(lats).ravel()
+    if lons.size == 0 or lats.size == 0:
+        raise ValueError("empty lon/lat")
+    z, s = C.c_int(), C.c_int()
+    lib().orc_utm_zone(lons, lats, lons.size, C.byref(z), C.byref(s))
+    return z.value, (" +south" if s.value else "")
+
+
+def utm_forward(lat_deg, lon_deg, zone, south):
+    lat, lon = _a(lat_deg).ravel(), _a(lon_deg).ravel()
+    e, n = np.empty_like(lat), np.empty_like(lat)
+    lib().orc_utm_forward(lat, lon, lat.size, int(zone), int(bool(south)), e, n)
+    return e, n
+
+
+def utm_inverse(easting, northing, zone, south):
+    e, n = _a(easting).ravel(), _a(northing).ravel()
+    lat, lon = np.empty_like(e), np.empty_like(e)
+    lib().orc_utm_inverse(e, n, e.size, int(zone), int(bool(south)), lat, lon)
+    return lat, lon
+
+
+# ---- EKFGPSSLAM.py:389-467 ---------------------------------------------------
+SIM3_NONE = 1
+
+
+def compute_sim3_transform(src, dst, return_flags=False):
+    src, dst = _a(src), _a(dst)
+    if src.shape != dst.shape or src.ndim != 2 or src.shape[1] != 3:
+        return (None, None, None, SIM3_NONE) if return_flags else (None, None, None)
+    R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+    rc = lib().orc_umeyama(src, dst, src.shape[0], R, t, C.byref(s))
+    if rc == SIM3_NONE:
+        return (None, None, None, rc) if return_flags else (None, None, None)
+    return (R, t, s.value, rc) if return_flags else (R, t, s.value)
+
+
+def draw_ransac_samples(n_points, min_samples, max_trials):
+    """The reference's RNG call (EKFGPSSLAM.py:405) on the legacy global stream."""
+    return np.stack([np.random.choice(n_points, min_samples, replace=False)
+                     for _ in range(max_trials)]).astype(np.int32)
+
+
+def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max_trials, min_inliers_needed,
+                                  sample_idx=None, return_mask=False):
+    src, dst = _a(src), _a(dst)
+    n = src.shape[0]
+    none = (None, None, None, None) if return_mask else (None, None, None)
+    if n < min_samples or src.shape != dst.shape:
+        return none
+    if sample_idx is None:
+        sample_idx = draw_ransac_samples(n, min_samples, max_trials)
+    sample_idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+    R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    nin = C.c_int64()
+    rc = lib().orc_sim3_ransac(src, dst, n, sample_idx, int(max_trials), int(min_samples),
+                               float(residual_threshold), int(min_inliers_needed), R, t, C.byref(s), mask,
+                               C.byref(nin))
+    if rc == SIM3_NONE:
+        return none
+    return (R, t, s.value, mask[:n].astype(bool)) if return_mask else (R, t, s.value)
+
+
+def transform_trajectory(positions, quaternions, R_mat, t_vec, scale_val):
+    p, q = _a(positions), _a(quaternions)
+    po, qo = np.empty_like(p), np.empty_like(q)
+    bad = lib().orc_transform_trajectory(p, q, p.shape[0], _a(R_mat), _a(t_vec), float(scale_val), po, qo)
+    if bad:
+        raise ValueError("Found zero norm quaternions in `quat`.")
+    return po, qo
+
+
+# ---- EKFGPSSLAM.py:679-935 ---------------------------------------------------
+def ekf_process_step(cfg, state, cov, gnss_prev, weight, current_steps, motion, gps_meas, avail, dt,
+                     override_steps=None):
+    """One ExtendedKalmanFilter.process_step with explicit state (returns new
+    state, cov, pred_state, pred_cov, gnss_prev, weight)."""
+    c = OrcConfig.from_dict(cfg)
+    st, cv = _a(state).copy(), _a(cov, (7, 7)).copy()
+    gp = C.c_int({None: -1, False: 0, True: 1}[gnss_prev])
+    w = C.c_double(weight)
+    ps, pc = np.empty(7), np.empty((7, 7))
+    z = _a(gps_meas if gps_meas is not None else [np.nan] * 3)
+    lib().orc_ekf_process_step(C.byref(c), st, cv, C.byref(gp), C.byref(w), int(current_steps), _a(motion[0]),
+                               _a(motion[1]), z, int(gps_meas is not None), int(bool(avail)), float(dt),
+                               -1 if override_steps is None else int(override_steps), ps, pc)
+    return st, cv, ps, pc, bool(gp.value), w.value
+
+
+def rts_smoother_segment(xf, Pf, xp, Pp):
+    xf, Pf, xp, Pp = _a(xf), _a(Pf), _a(xp), _a(Pp)
+    L = xf.shape[0]
+    xs, Ps = np.empty((L, 7)), np.empty((L, 7, 7))
+    lib().orc_rts_segment(xf, Pf.reshape(L, 49), xp, Pp.reshape(L, 49), L, xs, Ps.reshape(L, 49))
+    return xs, Ps
+
+
+def is_sharp_turn_in_segment(quats, stamps, thr_rad, return_rate=False):
+    q, t = _a(quats).reshape(-1, 4), _a(stamps).ravel()
+    mr = C.c_double()
+    r = bool(lib().orc_is_sharp_turn(q, t, q.shape[0], float(thr_rad), C.byref(mr)))
+    return (r, mr.value) if return_rate else r
+
+
+def apply_ekf_correction_aligned(ts, pos, quat, aligned, valid, sim3_pos0, sim3_quat0, cfg=None,
+                                 return_status=False):
+    """EKFGPSSLAM.py:831-935 after its dynamic_time_alignment call (:847)."""
+    ts, pos, quat, aligned = _a(ts).ravel(), _a(pos), _a(quat), _a(aligned)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    n = ts.size
+    po, qo = np.empty((n, 3)), np.empty((n, 4))
+    c = OrcConfig.from_dict(cfg)
+    st = lib().orc_apply_ekf_correction(ts, pos, quat, aligned, valid, n, _a(sim3_pos0), _a(sim3_quat0),
+                                        C.byref(c), po, qo)
+    return (po, qo, st) if return_status else (po, qo)
+
+
+def fuse_batch(ts, pos, quat, aligned, valid, init_pos, init_quat, cfg=None):
+    """B trajectories of equal length n, trajectory-major AoS."""
+    ts, pos, quat, aligned = _a(ts), _a(pos), _a(quat), _a(aligned)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    B, n = ts.shape
+    po, qo = np.empty((B, n, 3)), np.empty((B, n, 4))
+    st = np.zeros(B, dtype=np.int32)
+    c = OrcConfig.from_dict(cfg)
+    lib().orc_fuse_batch(ts, pos, quat, aligned, valid, B, n, _a(init_pos), _a(init_quat), C.byref(c), po, qo, st)
+    return po, qo, st
+
+
+def dynamic_time_alignment(slam_t, gps_t, gps_p, max_samples=500, max_gap=5.0):
+    st, gt, gp = _a(slam_t).ravel(), _a(gps_t).ravel(), _a(gps_p).reshape(-1, 3)
+    al = np.empty((st.size, 3))
+    va = np.zeros(max(st.size, 1), dtype=np.uint8)
+    lib().orc_dynamic_time_alignment(st, st.size, gt, gp, gt.size, int(max_samples), float(max_gap), al, va)
+    return al, va[:st.size].astype(bool)
