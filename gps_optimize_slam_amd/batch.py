@@ -1,0 +1,196 @@
+"""Batched device entry points: B independent trajectories resident in HBM as torch tensors.
+
+torch is plumbing here (device memory, the current HIP stream, torch.distributed for the N>1
+collect); every numerical stage is a libgsf.so kernel launched on torch's current stream.
+Additions to the reference's surface (which is single-trajectory): `*_batch` functions taking
+(B, N, .) trajectory-major or (N, ., B) time-major tensors -- SURVEY 8(b).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_TIME_MAJOR, LAYOUT_TRAJ_MAJOR, EkfConfig, GsfError, check  # noqa: F401
+from .ekfgpsslam import CONFIG
+
+_ctxs = {}
+
+
+def context(device=None):
+    """gsf context bound to torch's CURRENT stream on `device` (cached per device/stream)."""
+    if not torch.cuda.is_available():
+        raise GsfError("torch sees no GPU: the batched fusion path needs an MI355X (no CPU fallback)")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, stream)
+    if key not in _ctxs:
+        _ctxs[key] = _lib.Context(dev, stream)
+    return _ctxs[key]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, shape, name):
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"{name}: expected contiguous cuda {dtype} tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+
+
+def shapes(layout, B, N):
+    """tensor shapes of (ts, pos, quat, gps, valid) for a layout"""
+    if layout == LAYOUT_TIME_MAJOR:
+        return (N, B), (N, 3, B), (N, 4, B), (N, 3, B), (N, B)
+    return (B, N), (B, N, 3), (B, N, 4), (B, N, 3), (B, N)
+
+
+class TrajectoryBatch:
+    """B trajectories x N poses on one GPU: original SLAM track + time-aligned GNSS (+ Sim3-aligned first pose)."""
+
+    def __init__(self, layout, B, N, device="cuda"):
+        self.layout, self.B, self.N = int(layout), int(B), int(N)
+        s_ts, s_pos, s_quat, s_gps, s_val = shapes(layout, B, N)
+        f = dict(dtype=torch.float64, device=device)
+        self.ts, self.pos, self.quat, self.gps = torch.empty(s_ts, **f), torch.empty(s_pos, **f), torch.empty(s_quat, **f), torch.empty(s_gps, **f)
+        self.valid = torch.empty(s_val, dtype=torch.uint8, device=device)
+        self.init_pos, self.init_quat = torch.empty((B, 3), **f), torch.empty((B, 4), **f)
+
+    @classmethod
+    def synthetic(cls, B, N, layout=LAYOUT_TIME_MAJOR, seed=20250523, traj0=0, device="cuda"):
+        """Deterministic KITTI-04-shaped batch generated on the device (gsf_synth_batch_dev)."""
+        b = cls(layout, B, N, device)
+        check(_lib.load().gsf_synth_batch_dev(context().handle, b.layout, C.c_uint64(seed), int(traj0), b.B, b.N, _p(b.ts), _p(b.pos),
+                                              _p(b.quat), _p(b.gps), _p(b.valid), _p(b.init_pos), _p(b.init_quat)))
+        return b
+
+    @classmethod
+    def from_host(cls, ts, pos, quat, gps, valid, init_pos, init_quat, layout=LAYOUT_TRAJ_MAJOR, device="cuda"):
+        """(B,N,.) trajectory-major host arrays -> device batch in `layout`."""
+        B, N = ts.shape
+        tm = cls(LAYOUT_TRAJ_MAJOR, B, N, device)
+        for name, arr in (("ts", ts), ("pos", pos), ("quat", quat), ("gps", gps)):
+            getattr(tm, name).copy_(torch.as_tensor(arr, dtype=torch.float64).reshape(getattr(tm, name).shape))
+        tm.valid.copy_(torch.as_tensor(valid).to(torch.uint8).reshape(B, N))
+        tm.init_pos.copy_(torch.as_tensor(init_pos, dtype=torch.float64).reshape(B, 3))
+        tm.init_quat.copy_(torch.as_tensor(init_quat, dtype=torch.float64).reshape(B, 4))
+        return tm if layout == LAYOUT_TRAJ_MAJOR else tm.to_layout(layout)
+
+    def to_layout(self, layout):
+        if layout == self.layout:
+            return self
+        o = TrajectoryBatch(layout, self.B, self.N, self.ts.device)
+        L, h = _lib.load(), context().handle
+        fn = L.gsf_transpose_to_time_major_dev if layout == LAYOUT_TIME_MAJOR else L.gsf_transpose_to_traj_major_dev
+        for name, Cc, eb in (("ts", 1, 8), ("pos", 3, 8), ("quat", 4, 8), ("gps", 3, 8), ("valid", 1, 1)):
+            check(fn(h, _p(getattr(self, name)), _p(getattr(o, name)), self.B, self.N, Cc, eb))
+        o.init_pos.copy_(self.init_pos); o.init_quat.copy_(self.init_quat)
+        return o
+
+    def host_traj_major(self):
+        """-> dict of (B,N,.) numpy arrays (for the oracle / file output)"""
+        t = self.to_layout(LAYOUT_TRAJ_MAJOR)
+        torch.cuda.synchronize()
+        return {k: getattr(t, k).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
+
+
+class FusedPoses:
+    def __init__(self, layout, B, N, device="cuda"):
+        _, s_pos, s_quat, _, _ = shapes(layout, B, N)
+        self.layout, self.B, self.N = layout, B, N
+        self.pos = torch.empty(s_pos, dtype=torch.float64, device=device)
+        self.quat = torch.empty(s_quat, dtype=torch.float64, device=device)
+        self.status = torch.empty((B,), dtype=torch.int32, device=device)
+
+    def host_traj_major(self):
+        """-> (pos (B,N,3), quat (B,N,4), status (B,)) numpy"""
+        if self.layout == LAYOUT_TRAJ_MAJOR:
+            pos, quat = self.pos, self.quat
+        else:
+            pos = torch.empty((self.B, self.N, 3), dtype=torch.float64, device=self.pos.device)
+            quat = torch.empty((self.B, self.N, 4), dtype=torch.float64, device=self.pos.device)
+            L, h = _lib.load(), context().handle
+            check(L.gsf_transpose_to_traj_major_dev(h, _p(self.pos), _p(pos), self.B, self.N, 3, 8))
+            check(L.gsf_transpose_to_traj_major_dev(h, _p(self.quat), _p(quat), self.B, self.N, 4, 8))
+        torch.cuda.synchronize()
+        return pos.cpu().numpy(), quat.cpu().numpy(), self.status.cpu().numpy()
+
+
+def ekf_fuse_batch(batch, config=None, out=None):
+    """K4 over a device batch: apply_ekf_correction (EKFGPSSLAM.py:831-935, after its :847 alignment) per trajectory.
+    Asynchronous on torch's current stream; returns FusedPoses in the batch's layout."""
+    cfg = EkfConfig.from_config(config or CONFIG)
+    out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
+    check(_lib.load().gsf_ekf_fuse_batch_dev(context().handle, batch.layout, _p(batch.ts), _p(batch.pos), _p(batch.quat), _p(batch.gps),
+                                             _p(batch.valid), _p(batch.init_pos), _p(batch.init_quat), C.byref(cfg), batch.B, batch.N,
+                                             _p(out.pos), _p(out.quat), _p(out.status)))
+    return out
+
+
+def fuse_pipeline_batch(batch, config=None, out=None):
+    """Umeyama (valid rows) -> Sim3 of pose 0 -> EKF+RTS in one launch (steps 3-5 of EKFGPSSLAM.py:1002-1010, plain fit).
+    Returns (FusedPoses, R (B,9), t (B,3), s (B,))."""
+    cfg = EkfConfig.from_config(config or CONFIG)
+    out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
+    f = dict(dtype=torch.float64, device=batch.ts.device)
+    R, t, s = torch.empty((batch.B, 9), **f), torch.empty((batch.B, 3), **f), torch.empty((batch.B,), **f)
+    check(_lib.load().gsf_fuse_pipeline_batch_dev(context().handle, batch.layout, _p(batch.ts), _p(batch.pos), _p(batch.quat), _p(batch.gps),
+                                                  _p(batch.valid), C.byref(cfg), batch.B, batch.N, _p(R), _p(t), _p(s), _p(out.pos),
+                                                  _p(out.quat), _p(out.status)))
+    return out, R, t, s
+
+
+def sim3_umeyama_batch(src, dst, offsets=None, mask=None):
+    """K2 over device tensors.  src/dst: (total,3) with int64 offsets (B+1,), or (B,W,3) equal-size windows.
+    Returns R (B,9), t (B,3), s (B,), status (B,) int32."""
+    if src.dim() == 3:
+        B, W, _ = src.shape
+        offsets = torch.arange(0, (B + 1) * W, W, dtype=torch.int64, device=src.device)
+        src, dst = src.reshape(B * W, 3), dst.reshape(B * W, 3)
+    B = offsets.numel() - 1
+    _chk(src, torch.float64, src.shape, "src"); _chk(dst, torch.float64, src.shape, "dst")
+    f = dict(dtype=torch.float64, device=src.device)
+    R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
+    st = torch.empty((B,), dtype=torch.int32, device=src.device)
+    check(_lib.load().gsf_sim3_umeyama_batch_dev(context().handle, _p(src), _p(dst), _p(mask), _p(offsets), B, _p(R), _p(t), _p(s), _p(st)))
+    return R, t, s, st
+
+
+def sim3_ransac_batch(src, dst, offsets, sample_idx, residual_threshold, min_inliers_needed):
+    """K2b over device tensors; sample_idx (B,trials,ms) int32 drawn by the caller with the reference's RNG call."""
+    B, trials, ms = sample_idx.shape
+    f = dict(dtype=torch.float64, device=src.device)
+    R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
+    st, nin = torch.empty((B,), dtype=torch.int32, device=src.device), torch.empty((B,), dtype=torch.int32, device=src.device)
+    mask = torch.empty((src.shape[0],), dtype=torch.uint8, device=src.device)
+    check(_lib.load().gsf_sim3_ransac_batch_dev(context().handle, _p(src), _p(dst), _p(offsets), B, _p(sample_idx), trials, ms,
+                                                float(residual_threshold), int(min_inliers_needed), _p(R), _p(t), _p(s), _p(st), _p(mask), _p(nin)))
+    return R, t, s, st, mask, nin
+
+
+def apply_sim3_batch(pos, quat, offsets, R, t, s):
+    """K3 over device tensors: pos (total,3), quat (total,4) -> transformed copies (+ bad_quat flags (B,))."""
+    B = offsets.numel() - 1
+    po, qo = torch.empty_like(pos), torch.empty_like(quat)
+    bad = torch.empty((B,), dtype=torch.int32, device=pos.device)
+    check(_lib.load().gsf_apply_sim3_batch_dev(context().handle, _p(pos), _p(quat), _p(offsets), B, _p(R), _p(t), _p(s), _p(po), _p(qo), _p(bad)))
+    return po, qo, bad
+
+
+def utm_forward_batch(lat, lon, offsets, zone=None, south=None):
+    """K1 over device tensors (ragged trajectories).  zone/south None -> picked per trajectory like auto_utm_projection."""
+    B = offsets.numel() - 1
+    L, h = _lib.load(), context().handle
+    if zone is None:
+        zone = torch.empty((B,), dtype=torch.int32, device=lat.device)
+        south = torch.empty((B,), dtype=torch.int32, device=lat.device)
+        check(L.gsf_utm_zone_batch_dev(h, _p(lat), _p(lon), _p(offsets), B, _p(zone), _p(south)))
+    e, n = torch.empty_like(lat), torch.empty_like(lat)
+    check(L.gsf_utm_forward_batch_dev(h, _p(lat), _p(lon), _p(offsets), _p(zone), _p(south), B, _p(e), _p(n)))
+    return e, n, zone, south
+
+
+def utm_inverse_batch(e, n, offsets, zone, south):
+    B = offsets.numel() - 1
+    lat, lon = torch.empty_like(e), torch.empty_like(e)
+    check(_lib.load().gsf_utm_inverse_batch_dev(context().handle, _p(e), _p(n), _p(offsets), _p(zone), _p(south), B, _p(lat), _p(lon)))
+    return lat, lon

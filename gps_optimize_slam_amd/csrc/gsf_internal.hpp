@@ -1,0 +1,50 @@
+// gsf_internal.hpp -- context, error plumbing and layout indexing shared by the .hip units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gsf.h"
+#include "gsf_ekf_core.hpp"
+
+struct gsf_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    hipEvent_t ev0, ev1;
+    // scratch for the fused pipeline (R,t,s,status per trajectory + init poses), grown on demand
+    void* scratch;
+    size_t scratch_bytes;
+    int ekf_variant;       // tuning knob (gsf_set_option "ekf_variant")
+};
+
+namespace gsf {
+
+void set_error(const char* fmt, ...);
+int fail_hip(hipError_t e, const char* what);
+
+#define GSF_HIP(call)                                         \
+    do {                                                      \
+        hipError_t e__ = (call);                              \
+        if (e__ != hipSuccess) return gsf::fail_hip(e__, #call); \
+    } while (0)
+
+#define GSF_REQUIRE(cond, msg)                                \
+    do {                                                      \
+        if (!(cond)) { gsf::set_error("%s: %s", __func__, msg); return GSF_ERR_INVALID_ARG; } \
+    } while (0)
+
+// Element index of component c (of C) of pose i of trajectory b.
+template <int LAYOUT>
+struct Idx {
+    int64_t B, N;
+    __host__ __device__ __forceinline__ int64_t at(int64_t b, int64_t i, int c, int C) const
+    {
+        if (LAYOUT == GSF_LAYOUT_TIME_MAJOR) return (i * C + c) * B + b;
+        return (b * N + i) * C + c;
+    }
+};
+
+int ensure_scratch(gsf_ctx* ctx, size_t bytes);
+
+}  // namespace gsf

@@ -1,0 +1,322 @@
+// gsf_math.hpp -- FP64 building blocks of the GPS<->SLAM fusion kernels (gfx950).
+//
+// Everything here is branch-light inline code meant to live in VGPRs of one lane:
+// scalar-last quaternions [x,y,z,w] with SciPy's conventions, a 3x3
+// one-sided Jacobi SVD, the Umeyama closed form, and the Krueger transverse-Mercator
+// series.  The same header is compiled by g++ into a test-only host harness
+// (tests/host_harness.cpp) so the math can be checked against the oracle without a GPU;
+// the shipped library only ever runs it on the device.
+//
+// Reference lines ("ref :N") are /root/reference/EKFGPSSLAM.py.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSF_HD __host__ __device__ __forceinline__
+#define GSF_HD_COLD __host__ __device__ inline __attribute__((noinline))   // rare paths: keep them out of the hot loop's register budget
+#else
+#define GSF_HD inline
+#define GSF_HD_COLD inline
+#endif
+
+namespace gsf {
+
+struct Quat { double x, y, z, w; };
+struct Vec3 { double x, y, z; };
+
+GSF_HD double sq(double a) { return a * a; }
+
+// Rotation.from_quat: q/|q|; false if the norm is 0/NaN/inf (SciPy raises ValueError).
+GSF_HD bool quat_unit(const Quat& q, Quat& o)
+{
+    double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    double n = sqrt(n2);
+    bool ok = (n > 0.0) && (n < INFINITY);
+    double r = 1.0 / n;
+    o.x = q.x * r; o.y = q.y * r; o.z = q.z * r; o.w = q.w * r;
+    return ok;
+}
+GSF_HD Quat quat_conj(const Quat& q) { return Quat{ -q.x, -q.y, -q.z, q.w }; }
+// Rotation.__mul__ (Hamilton product p*q, "q first")
+GSF_HD Quat quat_mul(const Quat& p, const Quat& q)
+{
+    Quat o;
+    o.x = p.w * q.x + q.w * p.x + (p.y * q.z - p.z * q.y);
+    o.y = p.w * q.y + q.w * p.y + (p.z * q.x - p.x * q.z);
+    o.z = p.w * q.z + q.w * p.z + (p.x * q.y - p.y * q.x);
+    o.w = p.w * q.w - (p.x * q.x + p.y * q.y + p.z * q.z);
+    return o;
+}
+// Rotation.apply for a unit quaternion: as_matrix() @ v
+GSF_HD Vec3 quat_rotate(const Quat& q, const Vec3& v)
+{
+    double x2 = q.x * q.x, y2 = q.y * q.y, z2 = q.z * q.z, w2 = q.w * q.w;
+    double xy = q.x * q.y, zw = q.z * q.w, xz = q.x * q.z, yw = q.y * q.w, yz = q.y * q.z, xw = q.x * q.w;
+    Vec3 o;
+    o.x = (x2 - y2 - z2 + w2) * v.x + 2.0 * (xy - zw) * v.y + 2.0 * (xz + yw) * v.z;
+    o.y = 2.0 * (xy + zw) * v.x + (-x2 + y2 - z2 + w2) * v.y + 2.0 * (yz - xw) * v.z;
+    o.z = 2.0 * (xz - yw) * v.x + 2.0 * (yz + xw) * v.y + (-x2 - y2 + z2 + w2) * v.z;
+    return o;
+}
+// as_euler('zyx')[0] of a unit quaternion: atan2(-m01, m00)
+GSF_HD double quat_yaw_zyx(const Quat& q)
+{
+    double m00 = q.x * q.x - q.y * q.y - q.z * q.z + q.w * q.w;
+    double m01 = 2.0 * (q.x * q.y - q.z * q.w);
+    return atan2(-m01, m00);
+}
+// ExtendedKalmanFilter.normalize_quaternion, ref :697-700
+GSF_HD Quat ekf_normalize(const Quat& q)
+{
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    if (n > 1e-9) { double r = 1.0 / n; return Quat{ q.x * r, q.y * r, q.z * r, q.w * r }; }
+    return Quat{ 0.0, 0.0, 0.0, 1.0 };
+}
+// quaternion_nlerp, ref :94-105
+GSF_HD Quat quat_nlerp(const Quat& q1, Quat q2, double weight_q2)
+{
+    double dot = q1.x * q2.x + q1.y * q2.y + q1.z * q2.z + q1.w * q2.w;
+    if (dot < 0.0) { q2.x = -q2.x; q2.y = -q2.y; q2.z = -q2.z; q2.w = -q2.w; }
+    double w = fmin(fmax(weight_q2, 0.0), 1.0);
+    Quat qi{ (1.0 - w) * q1.x + w * q2.x, (1.0 - w) * q1.y + w * q2.y, (1.0 - w) * q1.z + w * q2.z,
+             (1.0 - w) * q1.w + w * q2.w };
+    double n = sqrt(qi.x * qi.x + qi.y * qi.y + qi.z * qi.z + qi.w * qi.w);
+    if (n < 1e-9) return (weight_q2 < 0.5) ? q1 : q2;
+    double r = 1.0 / n;
+    return Quat{ qi.x * r, qi.y * r, qi.z * r, qi.w * r };
+}
+// Rotation.from_matrix (largest of m00,m11,m22,trace), R row-major
+GSF_HD Quat quat_from_matrix(const double* M)
+{
+    double tr = M[0] + M[4] + M[8];
+    double q[4];
+    int c = 0; double best = M[0];
+    if (M[4] > best) { best = M[4]; c = 1; }
+    if (M[8] > best) { best = M[8]; c = 2; }
+    if (tr > best) { c = 3; }
+    if (c == 0)      { q[0] = 1.0 - tr + 2.0 * M[0]; q[1] = M[3] + M[1]; q[2] = M[6] + M[2]; q[3] = M[7] - M[5]; }
+    else if (c == 1) { q[1] = 1.0 - tr + 2.0 * M[4]; q[2] = M[7] + M[5]; q[0] = M[1] + M[3]; q[3] = M[2] - M[6]; }
+    else if (c == 2) { q[2] = 1.0 - tr + 2.0 * M[8]; q[0] = M[2] + M[6]; q[1] = M[5] + M[7]; q[3] = M[3] - M[1]; }
+    else             { q[0] = M[7] - M[5]; q[1] = M[2] - M[6]; q[2] = M[3] - M[1]; q[3] = 1.0 + tr; }
+    double r = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    return Quat{ q[0] * r, q[1] * r, q[2] * r, q[3] * r };
+}
+
+GSF_HD double det3(const double* M)
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ---------------------------------------------------------------------------------------
+// 3x3 SVD by one-sided (Hestenes) Jacobi: columns of A = H are rotated until mutually
+// orthogonal; V accumulates the rotations.  Relative accuracy even for sigma1 >> sigma3
+// (straight-road tracks), which an eigen-solve of H^T H would lose.  Outputs the pieces the
+// Umeyama closed form needs: U, V (column-major access via idx), S sorted descending.
+// ---------------------------------------------------------------------------------------
+struct Svd3 { double U[9], V[9], S[3]; };   // row-major 3x3; columns are the singular vectors
+
+GSF_HD void jacobi_pair(double* A, double* W, int p, int q, bool& rotated)
+{
+    double a = A[p] * A[p] + A[3 + p] * A[3 + p] + A[6 + p] * A[6 + p];
+    double b = A[q] * A[q] + A[3 + q] * A[3 + q] + A[6 + q] * A[6 + q];
+    double g = A[p] * A[q] + A[3 + p] * A[3 + q] + A[6 + p] * A[6 + q];
+    if (g == 0.0 || !(fabs(g) > 2.3e-16 * sqrt(a * b))) return;
+    rotated = true;
+    double zeta = (b - a) / (2.0 * g);
+    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double x = A[i * 3 + p], y = A[i * 3 + q];
+        A[i * 3 + p] = cs * x - sn * y; A[i * 3 + q] = sn * x + cs * y;
+        x = W[i * 3 + p]; y = W[i * 3 + q];
+        W[i * 3 + p] = cs * x - sn * y; W[i * 3 + q] = sn * x + cs * y;
+    }
+}
+
+GSF_HD void svd3(const double* H, Svd3& out)
+{
+    double A[9], W[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = H[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        jacobi_pair(A, W, 0, 1, rotated);
+        jacobi_pair(A, W, 0, 2, rotated);
+        jacobi_pair(A, W, 1, 2, rotated);
+        if (!rotated) break;
+    }
+    double s0 = sqrt(A[0] * A[0] + A[3] * A[3] + A[6] * A[6]);
+    double s1 = sqrt(A[1] * A[1] + A[4] * A[4] + A[7] * A[7]);
+    double s2 = sqrt(A[2] * A[2] + A[5] * A[5] + A[8] * A[8]);
+    // sort columns descending by singular value (3-element network on column indices)
+    int i0 = 0, i1 = 1, i2 = 2; double t0 = s0, t1 = s1, t2 = s2;
+    if (t1 > t0) { double t = t0; t0 = t1; t1 = t; int k = i0; i0 = i1; i1 = k; }
+    if (t2 > t1) { double t = t1; t1 = t2; t2 = t; int k = i1; i1 = i2; i2 = k; }
+    if (t1 > t0) { double t = t0; t0 = t1; t1 = t; int k = i0; i0 = i1; i1 = k; }
+    out.S[0] = t0; out.S[1] = t1; out.S[2] = t2;
+    double u0[3], u1[3], u2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        out.V[i * 3 + 0] = W[i * 3 + i0]; out.V[i * 3 + 1] = W[i * 3 + i1]; out.V[i * 3 + 2] = W[i * 3 + i2];
+        u0[i] = A[i * 3 + i0]; u1[i] = A[i * 3 + i1]; u2[i] = A[i * 3 + i2];
+    }
+    // U: normalise col 0, Gram-Schmidt col 1, col 2 = +-(u0 x u1); orthonormal even when rank-deficient
+    if (t0 > 0.0) { double r = 1.0 / t0; u0[0] *= r; u0[1] *= r; u0[2] *= r; }
+    else { u0[0] = 1.0; u0[1] = 0.0; u0[2] = 0.0; }
+    if (t1 > 1e-14 * t0 && t1 > 0.0) {
+        double d = u1[0] * u0[0] + u1[1] * u0[1] + u1[2] * u0[2];
+        u1[0] -= d * u0[0]; u1[1] -= d * u0[1]; u1[2] -= d * u0[2];
+    } else {
+        int m = 0; if (fabs(u0[1]) < fabs(u0[m])) m = 1; if (fabs(u0[2]) < fabs(u0[m])) m = 2;
+        double d = u0[m];
+        u1[0] = (m == 0 ? 1.0 : 0.0) - d * u0[0]; u1[1] = (m == 1 ? 1.0 : 0.0) - d * u0[1]; u1[2] = (m == 2 ? 1.0 : 0.0) - d * u0[2];
+    }
+    { double r = 1.0 / sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]); u1[0] *= r; u1[1] *= r; u1[2] *= r; }
+    double c0 = u0[1] * u1[2] - u0[2] * u1[1], c1 = u0[2] * u1[0] - u0[0] * u1[2], c2 = u0[0] * u1[1] - u0[1] * u1[0];
+    double sg = (c0 * u2[0] + c1 * u2[1] + c2 * u2[2] < 0.0) ? -1.0 : 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { out.U[i * 3 + 0] = u0[i]; out.U[i * 3 + 1] = u1[i]; }
+    out.U[2] = sg * c0; out.U[5] = sg * c1; out.U[8] = sg * c2;
+}
+
+// status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
+enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4 };
+
+// Umeyama closed form from the reduced moments, ref :439-451.
+//   H = sum src_c dst_c^T (row-major), ssq = sum |src_c|^2, sc/dc centroids, n points.
+GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, const double* dc, double n,
+                                double* R, double* t, double& scale)
+{
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) finite = finite && (fabs(H[i]) < INFINITY);   // NaN/inf -> LinAlgError -> None (:452)
+    if (!finite) return SIM3_NONE;
+    Svd3 s; svd3(H, s);
+    // R = Vt.T @ U.T = V U^T                                                   (:440)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] + s.V[r * 3 + 2] * s.U[c * 3 + 2];
+    if (det3(R) < 0.0) {                                                       // (:441-442) flip last row of Vt
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] - s.V[r * 3 + 2] * s.U[c * 3 + 2];
+    }
+    double var_src = ssq / n;                                                  // (:443)
+    double tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                            // (:444, Q12)
+    int32_t flags = SIM3_OK;
+    if (var_src < 1e-12) { scale = 1.0; flags |= SIM3_FLAG_VAR0; }             // (:445-447)
+    else {
+        scale = tr / (n * var_src);                                            // (:449)
+        if (scale <= 1e-6) { scale = 1.0; flags |= SIM3_FLAG_SMALL_SCALE; }    // (:450)
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        t[r] = dc[r] - scale * (R[r * 3] * sc[0] + R[r * 3 + 1] * sc[1] + R[r * 3 + 2] * sc[2]);   // (:451)
+    return flags;
+}
+
+// ---------------------------------------------------------------------------------------
+// WGS84 UTM, Krueger n-series to n^6 (replaces pyproj Proj("+proj=utm ..."), ref :267-270, :295)
+// ---------------------------------------------------------------------------------------
+struct TmConsts {
+    double e, k0A, alpha[6], beta[6];
+};
+GSF_HD TmConsts tm_consts()
+{
+    const double f = 1.0 / 298.257223563, a = 6378137.0, k0 = 0.9996;
+    const double n = f / (2.0 - f), n2 = n * n, n3 = n2 * n, n4 = n3 * n, n5 = n4 * n, n6 = n5 * n;
+    TmConsts c;
+    c.e = sqrt(f * (2.0 - f));
+    c.k0A = k0 * (a / (1.0 + n) * (1.0 + n2 / 4.0 + n4 / 64.0 + n6 / 256.0));
+    c.alpha[0] = n / 2 - 2 * n2 / 3 + 5 * n3 / 16 + 41 * n4 / 180 - 127 * n5 / 288 + 7891 * n6 / 37800;
+    c.alpha[1] = 13 * n2 / 48 - 3 * n3 / 5 + 557 * n4 / 1440 + 281 * n5 / 630 - 1983433 * n6 / 1935360;
+    c.alpha[2] = 61 * n3 / 240 - 103 * n4 / 140 + 15061 * n5 / 26880 + 167603 * n6 / 181440;
+    c.alpha[3] = 49561 * n4 / 161280 - 179 * n5 / 168 + 6601661 * n6 / 7257600;
+    c.alpha[4] = 34729 * n5 / 80640 - 3418889 * n6 / 1995840;
+    c.alpha[5] = 212378941 * n6 / 319334400;
+    c.beta[0] = n / 2 - 2 * n2 / 3 + 37 * n3 / 96 - n4 / 360 - 81 * n5 / 512 + 96199 * n6 / 604800;
+    c.beta[1] = n2 / 48 + n3 / 15 - 437 * n4 / 1440 + 46 * n5 / 105 - 1118711 * n6 / 3870720;
+    c.beta[2] = 17 * n3 / 480 - 37 * n4 / 840 - 209 * n5 / 4480 + 5569 * n6 / 90720;
+    c.beta[3] = 4397 * n4 / 161280 - 11 * n5 / 504 - 830251 * n6 / 7257600;
+    c.beta[4] = 4583 * n5 / 161280 - 108847 * n6 / 3991680;
+    c.beta[5] = 20648693 * n6 / 638668800;
+    return c;
+}
+
+// Sum_{j=1..6} c_j * {sin,cos}(2j x) * {cosh,sinh}(2j y) via angle-addition recurrences:
+// one sincos + one exp pair instead of 24 transcendental calls.
+GSF_HD void tm_series(const double* c, double x, double y, double& s_sin_cosh, double& s_cos_sinh)
+{
+    double s2 = sin(2.0 * x), c2 = cos(2.0 * x);
+    double ey = exp(2.0 * y), eyi = 1.0 / ey;
+    double ch2 = 0.5 * (ey + eyi), sh2 = 0.5 * (ey - eyi);
+    if (fabs(y) < 0.05) {             // sinh by series near 0 (eta is < 0.1 inside a UTM zone): no cancellation
+        double z = 2.0 * y, z2 = z * z;
+        sh2 = z * (1.0 + z2 / 6.0 * (1.0 + z2 / 20.0 * (1.0 + z2 / 42.0 * (1.0 + z2 / 72.0 * (1.0 + z2 / 110.0)))));
+    }
+    double sj = s2, cj = c2, chj = ch2, shj = sh2;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        a += c[j] * sj * chj;
+        b += c[j] * cj * shj;
+        double sn = sj * c2 + cj * s2, cn = cj * c2 - sj * s2;
+        double chn = chj * ch2 + shj * sh2, shn = shj * ch2 + chj * sh2;
+        sj = sn; cj = cn; chj = chn; shj = shn;
+    }
+    s_sin_cosh = a; s_cos_sinh = b;
+}
+
+// forward: degrees -> metres.  lon0_deg = 6*zone-183; fn = 0 or 1e7
+GSF_HD void utm_forward_point(const TmConsts& c, double lat_deg, double lon_deg, double lon0_deg, double fn,
+                              double& easting, double& northing)
+{
+    const double d2r = 0.017453292519943295769;
+    double phi = lat_deg * d2r, lam = lon_deg * d2r - lon0_deg * d2r;
+    double tau = tan(phi);
+    double t1 = sqrt(1.0 + tau * tau);
+    double sig = sinh(c.e * atanh(c.e * tau / t1));
+    double taup = tau * sqrt(1.0 + sig * sig) - sig * t1;
+    double cl = cos(lam), sl = sin(lam);
+    double xip = atan2(taup, cl);
+    double etap = asinh(sl / sqrt(taup * taup + cl * cl));
+    double a, b;
+    tm_series(c.alpha, xip, etap, a, b);
+    easting = 500000.0 + c.k0A * (etap + b);
+    northing = fn + c.k0A * (xip + a);
+}
+
+// inverse: metres -> degrees
+GSF_HD void utm_inverse_point(const TmConsts& c, double easting, double northing, double lon0_deg, double fn,
+                              double& lat_deg, double& lon_deg)
+{
+    const double r2d = 57.295779513082320877;
+    double xi = (northing - fn) / c.k0A, eta = (easting - 500000.0) / c.k0A;
+    double a, b;
+    tm_series(c.beta, xi, eta, a, b);
+    double xip = xi - a, etap = eta - b;
+    double sh = sinh(etap), cx = cos(xip);
+    double taup = sin(xip) / sqrt(sh * sh + cx * cx);
+    double lam = atan2(sh, cx);
+    double e2m = 1.0 - c.e * c.e;
+    double tau = taup / e2m;
+    for (int it = 0; it < 6; ++it) {           // Newton on tau'(tau) (Karney 2011 eqs 19-21); converges in 2-3
+        double t1 = sqrt(1.0 + tau * tau);
+        double sig = sinh(c.e * atanh(c.e * tau / t1));
+        double tpi = tau * sqrt(1.0 + sig * sig) - sig * t1;
+        double dtau = (taup - tpi) / sqrt(1.0 + tpi * tpi) * (1.0 + e2m * tau * tau) / (e2m * t1);
+        tau += dtau;
+        if (!(fabs(dtau) > 1e-15 * (1.0 + fabs(tau)))) break;
+    }
+    lat_deg = atan(tau) * r2d;
+    lon_deg = lam * r2d + lon0_deg;
+}
+
+}  // namespace gsf

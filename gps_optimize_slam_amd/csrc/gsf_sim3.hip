@@ -1,0 +1,331 @@
+// gsf_sim3.hip -- K2 Umeyama fit, K2b RANSAC wrapper, K3 apply-Sim3.
+//   compute_sim3_transform        EKFGPSSLAM.py:428-459
+//   compute_sim3_transform_robust EKFGPSSLAM.py:389-426
+//   transform_trajectory          EKFGPSSLAM.py:461-467
+//
+// K2: the fit is a reduction (centroids, then the 3x3 cross-covariance of the CENTRED points --
+// raw moments would cancel catastrophically at UTM magnitudes ~5e6 m) followed by a 3x3 SVD.
+// One wavefront reduces one point set with DPP/shuffle butterflies (no LDS, no atomics); the SVD +
+// closed form then runs LANE-PARALLEL: a 64-thread block owns 64 point sets, wave-reduces them one
+// after another and parks the 19 moments of set k in lane k's registers, so the ~500-instruction
+// Jacobi SVD is paid once per 64 sets instead of once per set.
+// K2b: one 256-thread block per point set; one hypothesis per thread (4-point fit entirely in
+// registers), all hypotheses score the same points so the reads are wave-broadcasts out of L1/L2.
+#include "gsf_internal.hpp"
+
+using namespace gsf;
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct Moments { double n, sc[3], dc[3], H[9], ssq; };
+
+// Wave-cooperative two-pass moments of rows [i0,i1) (optionally masked).  All lanes return the sums.
+__device__ __forceinline__ Moments wave_moments(const double* __restrict__ src, const double* __restrict__ dst,
+                                                const uint8_t* __restrict__ mask, int64_t i0, int64_t i1, int lane)
+{
+    Moments m;
+    double cnt = 0.0, s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0;
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        if (mask && !mask[i]) continue;
+        cnt += 1.0;
+        s0 += src[i * 3]; s1 += src[i * 3 + 1]; s2 += src[i * 3 + 2];
+        d0 += dst[i * 3]; d1 += dst[i * 3 + 1]; d2 += dst[i * 3 + 2];
+    }
+    m.n = wave_sum(cnt);
+    const double rn = 1.0 / m.n;
+    m.sc[0] = wave_sum(s0) * rn; m.sc[1] = wave_sum(s1) * rn; m.sc[2] = wave_sum(s2) * rn;
+    m.dc[0] = wave_sum(d0) * rn; m.dc[1] = wave_sum(d1) * rn; m.dc[2] = wave_sum(d2) * rn;
+    double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ssq = 0.0;
+    if (m.n >= 1.0) {
+        for (int64_t i = i0 + lane; i < i1; i += 64) {
+            if (mask && !mask[i]) continue;
+            const double a0 = src[i * 3] - m.sc[0], a1 = src[i * 3 + 1] - m.sc[1], a2 = src[i * 3 + 2] - m.sc[2];
+            const double b0 = dst[i * 3] - m.dc[0], b1 = dst[i * 3 + 1] - m.dc[1], b2 = dst[i * 3 + 2] - m.dc[2];
+            H[0] += a0 * b0; H[1] += a0 * b1; H[2] += a0 * b2;
+            H[3] += a1 * b0; H[4] += a1 * b1; H[5] += a1 * b2;
+            H[6] += a2 * b0; H[7] += a2 * b1; H[8] += a2 * b2;
+            ssq += a0 * a0 + a1 * a1 + a2 * a2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m.H[k] = wave_sum(H[k]);
+    m.ssq = wave_sum(ssq);
+    return m;
+}
+
+// 64 point sets per block: reduce set-by-set with the whole wave, finish lane-parallel.
+__global__ __launch_bounds__(64) void umeyama_batch_kernel(const double* __restrict__ src, const double* __restrict__ dst,
+                                                           const uint8_t* __restrict__ mask, const int64_t* __restrict__ offsets,
+                                                           int64_t B, double* __restrict__ R, double* __restrict__ t,
+                                                           double* __restrict__ s, int32_t* __restrict__ status)
+{
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    Moments mine; mine.n = 0.0;
+    const int nsets = (int)((B - b0 < 64) ? (B - b0) : 64);
+    for (int k = 0; k < nsets; ++k) {
+        const int64_t i0 = offsets[b0 + k], i1 = offsets[b0 + k + 1];
+        Moments m = wave_moments(src, dst, mask, i0, i1, lane);
+        if (lane == k) mine = m;
+    }
+    if (lane >= nsets) return;
+    const int64_t b = b0 + lane;
+    double Rb[9], tb[3], sb = NAN; int32_t st;
+    if (mine.n < 3.0) st = SIM3_NONE;                                        // ref :430
+    else st = umeyama_finalize(mine.H, mine.ssq, mine.sc, mine.dc, mine.n, Rb, tb, sb);
+    if (st == SIM3_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rb[k] = NAN;
+        tb[0] = tb[1] = tb[2] = NAN; sb = NAN;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[b * 9 + k] = Rb[k];
+    t[b * 3] = tb[0]; t[b * 3 + 1] = tb[1]; t[b * 3 + 2] = tb[2];
+    s[b] = sb; status[b] = st;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int RANSAC_THREADS = 256;
+constexpr int RANSAC_MAX_SAMPLES = 8;
+
+__device__ __forceinline__ double block_sum(double v, double* sh, int tid)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < RANSAC_THREADS / 64; ++w) r += sh[w];
+    return r;
+}
+
+// Fit on the `ms` sampled rows, sequential sums like the reference's np.mean / matmul on 4 rows.
+__device__ __forceinline__ int32_t fit_sample(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0,
+                                              const int32_t* __restrict__ idx, int ms, double* R, double* t, double& s)
+{
+    double sc[3] = { 0, 0, 0 }, dc[3] = { 0, 0, 0 };
+    for (int k = 0; k < ms; ++k) {
+        const int64_t r = i0 + idx[k];
+        sc[0] += src[r * 3]; sc[1] += src[r * 3 + 1]; sc[2] += src[r * 3 + 2];
+        dc[0] += dst[r * 3]; dc[1] += dst[r * 3 + 1]; dc[2] += dst[r * 3 + 2];
+    }
+    const double n = (double)ms;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sc[c] /= n; dc[c] /= n; }
+    double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ssq = 0.0;
+    for (int k = 0; k < ms; ++k) {
+        const int64_t r = i0 + idx[k];
+        const double a0 = src[r * 3] - sc[0], a1 = src[r * 3 + 1] - sc[1], a2 = src[r * 3 + 2] - sc[2];
+        const double b0 = dst[r * 3] - dc[0], b1 = dst[r * 3 + 1] - dc[1], b2 = dst[r * 3 + 2] - dc[2];
+        H[0] += a0 * b0; H[1] += a0 * b1; H[2] += a0 * b2;
+        H[3] += a1 * b0; H[4] += a1 * b1; H[5] += a1 * b2;
+        H[6] += a2 * b0; H[7] += a2 * b1; H[8] += a2 * b2;
+        ssq += a0 * a0 + a1 * a1 + a2 * a2;
+    }
+    if (ms < 3) return SIM3_NONE;
+    return umeyama_finalize(H, ssq, sc, dc, n, R, t, s);
+}
+
+__device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
+                                          const double* R, const double* t, double s, double thr)
+{
+    const double x = src[r * 3], y = src[r * 3 + 1], z = src[r * 3 + 2];
+    const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - dst[r * 3];
+    const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - dst[r * 3 + 1];
+    const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - dst[r * 3 + 2];
+    return sqrt(dx * dx + dy * dy + dz * dz) < thr;                           // ref :410-411
+}
+
+__global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
+    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
+    double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
+    int32_t* __restrict__ n_inliers)
+{
+    __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
+    __shared__ double sh_fit[13];
+    __shared__ double sh_red[RANSAC_THREADS / 64];
+    __shared__ int sh_cnt[RANSAC_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1], n = i1 - i0;
+    auto write_none = [&](int32_t best) {
+        if (tid == 0) {
+            for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
+            tout[b * 3] = tout[b * 3 + 1] = tout[b * 3 + 2] = NAN; sout[b] = NAN;
+            status[b] = SIM3_NONE; n_inliers[b] = best;
+        }
+    };
+    if (n < ms) {                                                            // ref :395-397
+        for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
+        write_none(-1);
+        return;
+    }
+    // ---- hypotheses: one per thread, strided over the trials (ref :404-414)
+    const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
+    long long best_cnt = -1; int best_trial = 0x7fffffff;
+    for (int tr = tid; tr < trials; tr += RANSAC_THREADS) {
+        double R[9], t[3], s;
+        if (fit_sample(src, dst, i0, my_idx + (size_t)tr * ms, ms, R, t, s) == SIM3_NONE) continue;   // :408
+        long long cnt = 0;
+        for (int64_t r = i0; r < i1; ++r) cnt += is_inlier(src, dst, r, R, t, s, thr) ? 1 : 0;
+        if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
+    }
+    // block arg-max: highest count, then lowest trial index
+    unsigned long long key = ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(key, o, 64);
+        key = other > key ? other : key;
+    }
+    if ((tid & 63) == 0) sh_key[tid >> 6] = key;
+    __syncthreads();
+    key = sh_key[0];
+#pragma unroll
+    for (int w = 1; w < RANSAC_THREADS / 64; ++w) key = sh_key[w] > key ? sh_key[w] : key;
+    const long long win_cnt = (long long)(key >> 32) - 1;
+    const int win_trial = 0x7fffffff - (int)(key & 0xffffffffull);
+    if (win_cnt < 0) {                                                       // every trial was degenerate
+        for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
+        write_none(-1);
+        return;
+    }
+    // ---- winner's mask
+    if (tid == 0) {
+        double R[9], t[3], s;
+        fit_sample(src, dst, i0, my_idx + (size_t)win_trial * ms, ms, R, t, s);
+        for (int k = 0; k < 9; ++k) sh_fit[k] = R[k];
+        sh_fit[9] = t[0]; sh_fit[10] = t[1]; sh_fit[11] = t[2]; sh_fit[12] = s;
+    }
+    __syncthreads();
+    double Rw[9], tw[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rw[k] = sh_fit[k];
+    tw[0] = sh_fit[9]; tw[1] = sh_fit[10]; tw[2] = sh_fit[11];
+    const double sw = sh_fit[12];
+    for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = is_inlier(src, dst, i, Rw, tw, sw, thr) ? 1 : 0;
+    if (win_cnt < (long long)min_inliers) { write_none((int32_t)win_cnt); return; }   // ref :416-418
+    __syncthreads();                                                         // mask visible block-wide (same CU)
+    // ---- final fit on the inliers (ref :420-421): block-wide two-pass moments
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) {
+        if (!inlier_mask[i]) continue;
+        acc[0] += 1.0;
+        acc[1] += src[i * 3]; acc[2] += src[i * 3 + 1]; acc[3] += src[i * 3 + 2];
+        acc[4] += dst[i * 3]; acc[5] += dst[i * 3 + 1]; acc[6] += dst[i * 3 + 2];
+    }
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tot[k] = block_sum(acc[k], sh_red, tid);
+    const double cntf = tot[0];
+    double sc[3] = { tot[1] / cntf, tot[2] / cntf, tot[3] / cntf }, dc[3] = { tot[4] / cntf, tot[5] / cntf, tot[6] / cntf };
+    double h[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) {
+        if (!inlier_mask[i]) continue;
+        const double a0 = src[i * 3] - sc[0], a1 = src[i * 3 + 1] - sc[1], a2 = src[i * 3 + 2] - sc[2];
+        const double b0 = dst[i * 3] - dc[0], b1 = dst[i * 3 + 1] - dc[1], b2 = dst[i * 3 + 2] - dc[2];
+        h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
+        h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
+        h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
+        h[9] += a0 * a0 + a1 * a1 + a2 * a2;
+    }
+    double H[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) H[k] = block_sum(h[k], sh_red, tid);
+    if (tid == 0) {
+        double R[9], t[3], s = NAN; int32_t st;
+        if (cntf < 3.0) st = SIM3_NONE;
+        else st = umeyama_finalize(H, H[9], sc, dc, cntf, R, t, s);
+        if (st == SIM3_NONE) { for (int k = 0; k < 9; ++k) R[k] = NAN; t[0] = t[1] = t[2] = NAN; s = NAN; }
+        for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = R[k];
+        tout[b * 3] = t[0]; tout[b * 3 + 1] = t[1]; tout[b * 3 + 2] = t[2]; sout[b] = s;
+        status[b] = st; n_inliers[b] = (int32_t)win_cnt;
+    }
+    (void)sh_cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_sim3_kernel(const double* __restrict__ pos, const double* __restrict__ quat,
+                                                         const int64_t* __restrict__ offsets, const double* __restrict__ R,
+                                                         const double* __restrict__ t, const double* __restrict__ s,
+                                                         double* __restrict__ pos_out, double* __restrict__ quat_out,
+                                                         int32_t* __restrict__ bad_quat)
+{
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    double Rb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rb[k] = R[b * 9 + k];
+    const double t0 = t[b * 3], t1 = t[b * 3 + 1], t2 = t[b * 3 + 2], sb = s[b];
+    const Quat qR = quat_from_matrix(Rb);                                    // ref :465
+    int bad = 0;
+    for (int64_t i = i0 + blockIdx.y * blockDim.x + threadIdx.x; i < i1; i += (int64_t)blockDim.x * gridDim.y) {
+        const double x = pos[i * 3], y = pos[i * 3 + 1], z = pos[i * 3 + 2];
+        pos_out[i * 3] = sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + t0;      // ref :464
+        pos_out[i * 3 + 1] = sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + t1;
+        pos_out[i * 3 + 2] = sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + t2;
+        Quat qn; const bool ok = quat_unit(Quat{ quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3] }, qn);
+        Quat o = quat_mul(qR, qn);                                           // ref :466
+        if (!ok) { o = Quat{ NAN, NAN, NAN, NAN }; bad = 1; }
+        quat_out[i * 4] = o.x; quat_out[i * 4 + 1] = o.y; quat_out[i * 4 + 2] = o.z; quat_out[i * 4 + 3] = o.w;
+    }
+    if (bad_quat && bad) atomicOr(&bad_quat[b], 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsf_sim3_umeyama_batch_dev(gsf_ctx* ctx, const double* src, const double* dst, const uint8_t* mask, const int64_t* offsets,
+                               int64_t B, double* R, double* t, double* s, int32_t* status)
+{
+    GSF_REQUIRE(ctx && offsets && R && t && s && status, "NULL argument");
+    GSF_REQUIRE(B >= 0, "negative B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(umeyama_batch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, src, dst, mask, offsets, B, R, t, s, status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_sim3_ransac_batch_dev(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, int64_t B,
+                              const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers,
+                              double* R, double* t, double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
+{
+    GSF_REQUIRE(ctx && offsets && R && t && s && status && inlier_mask && n_inliers, "NULL argument");
+    GSF_REQUIRE(B >= 0 && trials >= 0, "negative B or trials");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= RANSAC_MAX_SAMPLES, "min_samples must be in [1,8]");
+    GSF_REQUIRE(trials == 0 || sample_idx, "sample_idx is NULL");
+    GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, sample_idx,
+                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_apply_sim3_batch_dev(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R,
+                             const double* t, const double* s, double* pos_out, double* quat_out, int32_t* bad_quat)
+{
+    GSF_REQUIRE(ctx && offsets && R && t && s, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    if (bad_quat) GSF_HIP(hipMemsetAsync(bad_quat, 0, (size_t)B * 4, ctx->stream));
+    // few trajectories -> several blocks per trajectory so a single long track still fills the chip
+    const unsigned gy = B >= 2048 ? 1u : (B >= 256 ? 4u : 64u);
+    hipLaunchKernelGGL(apply_sim3_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// gsf_utm.hip -- K1: batched WGS84 <-> UTM (replaces the pyproj/PROJ calls of load_gps_data,
+// EKFGPSSLAM.py:266-271, and utm_to_wgs84, :291-296) plus the zone pick of auto_utm_projection (:127-134).
+//
+// One lane per point, SoA lat[]/lon[] so a wave reads two contiguous 512-B rows and writes two.
+// This kernel is FP64-VALU-bound, not HBM-bound (~10 libm-class calls per point against 32 B of
+// traffic): the Krueger series is evaluated with angle-addition recurrences so that only one
+// sincos and one exp are paid for the six harmonics (gsf_math.hpp: tm_series).
+#include "gsf_internal.hpp"
+
+using namespace gsf;
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// mean(lon), mean(lat) per trajectory -> zone / hemisphere (ref :131-133)
+__global__ __launch_bounds__(256) void utm_zone_kernel(const double* __restrict__ lat, const double* __restrict__ lon,
+                                                       const int64_t* __restrict__ offsets, int32_t* __restrict__ zone,
+                                                       int32_t* __restrict__ south)
+{
+    __shared__ double sh[2][4];
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    double sl = 0.0, sp = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { sl += lon[i]; sp += lat[i]; }
+    sl = wave_sum(sl); sp = wave_sum(sp);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sl; sh[1][threadIdx.x >> 6] = sp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)(i1 - i0);
+        const double ml = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / n, mp = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / n;
+        zone[b] = (i1 > i0) ? (int32_t)(floor((ml + 180.0) / 6.0) + 1.0) : 0;      // int((mean+180)//6+1)
+        south[b] = (i1 > i0 && mp < 0.0) ? 1 : 0;
+    }
+}
+
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void utm_kernel(const double* __restrict__ a, const double* __restrict__ bb,
+                                                  const int64_t* __restrict__ offsets, const int32_t* __restrict__ zone,
+                                                  const int32_t* __restrict__ south, double* __restrict__ o1, double* __restrict__ o2)
+{
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    const double lon0 = 6.0 * (double)zone[b] - 183.0;
+    const double fn = south[b] ? 10000000.0 : 0.0;
+    const TmConsts c = tm_consts();
+    for (int64_t i = i0 + blockIdx.y * blockDim.x + threadIdx.x; i < i1; i += (int64_t)blockDim.x * gridDim.y) {
+        double r1, r2;
+        if (!INVERSE) {
+            const double la = a[i], lo = bb[i];
+            // validity mask of ref :259 -- rows the reference drops come back as NaN
+            const bool ok = (fabs(la) <= 90.0) && (fabs(lo) <= 180.0) && (la != 0.0) && (lo != 0.0);
+            utm_forward_point(c, la, lo, lon0, fn, r1, r2);
+            if (!ok) { r1 = NAN; r2 = NAN; }
+        } else {
+            utm_inverse_point(c, a[i], bb[i], lon0, fn, r1, r2);
+        }
+        o1[i] = r1; o2[i] = r2;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsf_utm_zone_batch_dev(gsf_ctx* ctx, const double* lat, const double* lon, const int64_t* offsets, int64_t B, int32_t* zone,
+                           int32_t* south)
+{
+    GSF_REQUIRE(ctx && offsets && zone && south, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(utm_zone_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, lat, lon, offsets, zone, south);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+static unsigned blocks_per_traj(int64_t B) { return B >= 2048 ? 1u : (B >= 256 ? 4u : 64u); }
+
+int gsf_utm_forward_batch_dev(gsf_ctx* ctx, const double* lat, const double* lon, const int64_t* offsets, const int32_t* zone,
+                              const int32_t* south, int64_t B, double* easting, double* northing)
+{
+    GSF_REQUIRE(ctx && offsets && zone && south, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(utm_kernel<false>, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, lat, lon, offsets, zone, south, easting, northing);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_utm_inverse_batch_dev(gsf_ctx* ctx, const double* easting, const double* northing, const int64_t* offsets, const int32_t* zone,
+                              const int32_t* south, int64_t B, double* lat, double* lon)
+{
+    GSF_REQUIRE(ctx && offsets && zone && south, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(utm_kernel<true>, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, easting, northing, offsets, zone, south, lat, lon);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+}  // extern "C"

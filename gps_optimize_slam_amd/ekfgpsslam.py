@@ -1,0 +1,409 @@
+"""Drop-in surface of the reference's EKFGPSSLAM.py hot path, backed by the gfx950 kernels.
+
+Same function names, argument order, return conventions and error behaviour as the reference
+(/root/reference/EKFGPSSLAM.py, lines cited per function); arrays are C-order float64 NumPy,
+quaternions scalar-last.  Every numerical stage runs on the GPU through libgsf.so -- there is no
+CPU fallback: without the library / a device the first call raises GsfError.
+
+What stays host Python, as in the reference: text I/O (np.loadtxt/np.savetxt), the RNG draws of the
+Sim3 RANSAC (np.random.choice on the legacy global stream, so a seeded run reproduces the
+reference's), and -- until their device kernels land -- the time alignment
+(scipy interp1d, exactly the reference's call) and the optional sklearn GPS outlier filter.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EkfConfig, GsfError, check, f64, hptr  # noqa: F401
+
+# EKFGPSSLAM.py:22-71
+CONFIG = {
+    "ekf": {
+        "initial_cov_diag": [0.1, 0.1, 0.1, 0.01, 0.01, 0.01, 0.01],
+        "process_noise_diag": [0.1, 0.1, 0.7, 0.01, 0.01, 0.01, 0.01],
+        "meas_noise_diag": [0.2, 0.2, 0.2],
+        "transition_steps": 10,
+    },
+    "sim3_ransac": {
+        "min_samples": 4,
+        "residual_threshold": 4.0,
+        "max_trials": 1000,
+        "min_inliers_needed": 4,
+        "max_initial_duration": 180.0,
+    },
+    "gps_filtering_ransac": {
+        "enabled": True, "use_sliding_window": True, "window_duration_seconds": 15.0, "window_step_factor": 0.5,
+        "polynomial_degree": 2, "min_samples": 6, "residual_threshold_meters": 10.0, "max_trials": 50,
+    },
+    "time_alignment": {"max_samples_for_corr": 500, "max_gps_gap_threshold": 5.0},
+    "ground_truth_gps_filtering": {
+        "enabled": False, "use_sliding_window": True, "window_duration_seconds": 15.0, "window_step_factor": 0.5,
+        "polynomial_degree": 2, "min_samples": 6, "residual_threshold_meters": 5.0, "max_trials": 50,
+    },
+    "rts_decision": {"sharp_turn_yaw_rate_threshold_deg_per_sec": 45.0, "default_ekf_transition_steps_on_sharp_turn": 0},
+}
+
+
+def _ctx():
+    return _lib.default_context()
+
+
+# ---------------------------------------------------------------------------- I/O (EKFGPSSLAM.py:110-125, :1091-1104)
+def load_slam_trajectory(txt_path):
+    """TUM trajectory -> {'timestamps','positions','quaternions'}; ValueError on any problem (ref :110-125)."""
+    try:
+        data = np.loadtxt(txt_path)
+        if data.ndim == 1:
+            data = data.reshape(1, -1)
+        if data.shape[1] != 8:
+            raise ValueError(f"SLAM file format error: expected 8 columns (ts x y z qx qy qz qw), got {data.shape[1]}")
+        return {"timestamps": data[:, 0].astype(float), "positions": data[:, 1:4].astype(float),
+                "quaternions": data[:, 4:8].astype(float)}
+    except FileNotFoundError:
+        raise ValueError(f"SLAM file not found: {txt_path}")
+    except Exception as e:
+        raise ValueError(f"SLAM data load/parse failed ({txt_path}): {e}")
+
+
+def save_tum_utm(path, timestamps, positions, quaternions):
+    """The reference's UTM TUM writer (ref :1091-1092): %.6f x4, %.8f x4, header without '#'."""
+    out = np.column_stack((timestamps, positions, quaternions))
+    np.savetxt(path, out, fmt=["%.6f"] + ["%.6f"] * 3 + ["%.8f"] * 4, header="timestamp x y z qx qy qz qw (UTM)", comments="")
+
+
+def save_tum_wgs84(path, timestamps, lonlatalt, quaternions):
+    """The reference's WGS84 writer (ref :1097-1101)."""
+    out = np.column_stack((timestamps, lonlatalt, quaternions))
+    np.savetxt(path, out, fmt=["%.6f"] + ["%.8f", "%.8f", "%.3f"] + ["%.8f"] * 4, header="timestamp lon lat alt qx qy qz qw (WGS84)", comments="")
+
+
+# ---------------------------------------------------------------------------- geodesy (EKFGPSSLAM.py:127-134, :249-296)
+def auto_utm_projection(lons, lats):
+    """(zone:int, hemisphere:str) from mean lon / mean lat (ref :127-134)."""
+    lons, lats = np.asarray(lons), np.asarray(lats)
+    if lons.size == 0 or lats.size == 0:
+        raise ValueError("lon/lat arrays must not be empty to pick a UTM zone")
+    central_lon = np.mean(lons)
+    zone = int((central_lon + 180) // 6 + 1)
+    hemisphere = " +south" if np.mean(lats) < 0 else ""
+    return zone, hemisphere
+
+
+class UtmProjector:
+    """Callable stand-in for pyproj.Proj("+proj=utm +zone=Z[ +south] +ellps=WGS84 ...") (ref :267-270, :295):
+    projector(lons, lats) -> (E, N); projector(x, y, inverse=True) -> (lons, lats).  Runs K1 on the GPU."""
+
+    def __init__(self, zone, south):
+        self.zone, self.south = int(zone), bool(south)
+        self.srs = f"+proj=utm +zone={self.zone}{' +south' if self.south else ''} +ellps=WGS84 +datum=WGS84 +units=m +no_defs"
+
+    def __call__(self, a, b, inverse=False):
+        a, b = f64(a).ravel(), f64(b).ravel()
+        if a.shape != b.shape:
+            raise ValueError("x/y (lon/lat) must have the same length")
+        o1, o2 = np.empty_like(a), np.empty_like(a)
+        L = _lib.load()
+        if not inverse:      # a = lons, b = lats
+            check(L.gsf_utm_forward(_ctx().handle, hptr(b), hptr(a), a.size, self.zone, int(self.south), hptr(o1), hptr(o2)))
+            return o1, o2    # (E, N)
+        check(L.gsf_utm_inverse(_ctx().handle, hptr(a), hptr(b), a.size, self.zone, int(self.south), hptr(o1), hptr(o2)))
+        return o2, o1        # gsf returns (lat, lon); pyproj returns (lon, lat)
+
+
+def filter_gps_outliers_ransac(times, positions, config):
+    """Host-side restatement of the reference's optional GPS pre-filter (ref :136-247): per-axis degree-d polynomial
+    RANSAC (scikit-learn's RANSACRegressor, global legacy RNG), AND across axes; either one global fit or sliding
+    windows [t, t+W) advanced by W*step_factor with one extra tail window, OR across windows -- rows never inside a
+    fitted window are dropped.  SURVEY 8(f) next-3: not a kernel yet; needs scikit-learn exactly as the reference does."""
+    if not config.get("enabled", False):
+        return times, positions
+    n_points, need = len(times), config["min_samples"]
+    if n_points < need:
+        return times, positions
+    from sklearn.linear_model import RANSACRegressor
+    from sklearn.pipeline import make_pipeline
+    from sklearn.preprocessing import PolynomialFeatures
+
+    def axes_mask(t, p):
+        per_axis = []
+        for ax in range(positions.shape[1]):
+            model = make_pipeline(PolynomialFeatures(degree=config["polynomial_degree"]),
+                                  RANSACRegressor(min_samples=need, residual_threshold=config["residual_threshold_meters"],
+                                                  max_trials=config["max_trials"]))
+            model.fit(t.reshape(-1, 1), p[:, ax])
+            per_axis.append(model[-1].inlier_mask_)
+        return np.logical_and.reduce(per_axis)
+
+    if not config.get("use_sliding_window", False):                      # ref :148-182
+        try:
+            keep = axes_mask(times, positions)
+            return times[keep], positions[keep]
+        except Exception:
+            return times, positions
+    width = config["window_duration_seconds"]                            # ref :183-247
+    stride = width * config["window_step_factor"]
+    keep = np.zeros(n_points, dtype=bool)
+    t_first, t_last = times[0], times[-1]
+    w0 = t_first
+    while w0 < t_last:
+        w1 = w0 + width
+        rows = np.where((times >= w0) & (times < w1))[0]
+        if len(rows) >= need:
+            try:
+                keep[rows[axes_mask(times[rows], positions[rows])]] = True
+            except Exception:
+                pass                                                     # a failed window marks nothing (ref :228-229)
+        if stride <= 1e-6:
+            later = np.where(times > w0)[0]
+            if len(later) == 0:
+                break
+            w0 = times[later[0]]
+        else:
+            w0 += stride
+        if w0 >= t_last and times[-1] >= w1:                             # one tail window ending just past the last stamp
+            w0 = max(t_first, times[-1] - width + 1e-6)
+    return times[keep], positions[keep]
+
+
+def load_gps_data(txt_path, data_label="GPS", filter_config_override=None):
+    """GPS text file -> {'timestamps','positions'(UTM E,N,alt),'utm_zone','projector'}; ValueError on failure
+    (ref :249-289).  Columns are read as ts, lat, lon, alt -- cols 0,1,2,3 (ref :258)."""
+    try:
+        try:
+            raw = np.loadtxt(txt_path, delimiter=" ")
+        except ValueError:
+            raw = np.loadtxt(txt_path, delimiter=",")
+        if raw.ndim == 1:
+            raw = raw.reshape(1, -1)
+        if raw.shape[1] < 4:
+            raise ValueError(f"{data_label} file needs at least 4 columns (ts lat lon alt), got {raw.shape[1]}")
+        ts, lats, lons, alts = raw[:, 0], raw[:, 1], raw[:, 2], raw[:, 3]
+        valid = (np.abs(lats) <= 90) & (np.abs(lons) <= 180) & (lats != 0) & (lons != 0)          # ref :259
+        if not np.all(valid):
+            ts, lats, lons, alts = ts[valid], lats[valid], lons[valid], alts[valid]
+            if len(ts) == 0:
+                raise ValueError(f"{data_label}: no valid GPS rows after the lat/lon range filter")
+        zone, hemi = auto_utm_projection(lons, lats)
+        projector = UtmProjector(zone, "south" in hemi)
+        x, y = projector(lons, lats)                                                              # K1 on the GPU
+        utm = np.column_stack((x, y, alts))
+        fcfg = filter_config_override if filter_config_override is not None else CONFIG["gps_filtering_ransac"]
+        ft, fp = filter_gps_outliers_ransac(ts, utm, fcfg)
+        if len(ft) < 2:
+            raise ValueError(f"{data_label}: fewer than 2 points left after the RANSAC filter")
+        return {"timestamps": ft, "positions": fp, "utm_zone": f"{zone}{'S' if 'south' in hemi else 'N'}", "projector": projector}
+    except FileNotFoundError:
+        raise ValueError(f"{data_label} file not found: {txt_path}")
+    except GsfError:
+        raise
+    except Exception as e:
+        raise ValueError(f"{data_label} data processing failed: {e}")
+
+
+def utm_to_wgs84(utm_points, projector):
+    """UTM (X,Y,Z) -> (lon, lat, alt) (ref :291-296)."""
+    utm_points = np.asarray(utm_points)
+    if utm_points.ndim != 2 or utm_points.shape[1] != 3:
+        raise ValueError("UTM points must be an Nx3 array (X, Y, Z)")
+    if not isinstance(projector, UtmProjector):
+        raise TypeError("projector must be the UtmProjector returned by load_gps_data")
+    lons, lats = projector(utm_points[:, 0], utm_points[:, 1], inverse=True)
+    return np.column_stack((lons, lats, utm_points[:, 2]))
+
+
+# ---------------------------------------------------------------------------- time alignment (EKFGPSSLAM.py:301-387)
+def estimate_time_offset(slam_times, gps_times, max_samples):
+    """Clock offset by cross-correlation (ref :301-323).  The reference correlates two *linspaces*, which peaks
+    at lag 0 for any input: the result is exactly 0.0; only the early-outs are kept."""
+    return 0.0
+
+
+def dynamic_time_alignment(slam_data, gps_data_source, time_align_config):
+    """GPS positions interpolated onto the SLAM stamps, per gap-free segment (ref :325-387).
+    Returns (aligned (N,3) with NaN where unavailable, valid_mask (N,) bool).  Host-side for now (next-1)."""
+    from scipy.interpolate import interp1d
+    slam_times, gps_times, gps_positions = slam_data["timestamps"], gps_data_source["timestamps"], gps_data_source["positions"]
+    gap_thr = time_align_config["max_gps_gap_threshold"]
+    n_slam, n_gps = len(slam_times), len(gps_times)
+    aligned, valid = np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
+    if n_slam == 0 or n_gps < 2:
+        return aligned, valid
+    adj = gps_times + estimate_time_offset(slam_times, gps_times, time_align_config["max_samples_for_corr"])
+    try:
+        order = np.argsort(adj)
+        ts, ps = adj[order], gps_positions[order]
+        uniq, first = np.unique(ts, return_index=True)
+        if len(uniq) < 2:
+            return aligned, valid
+        if len(uniq) < n_gps:
+            ts, ps = uniq, ps[first]
+        gaps = np.where(np.diff(ts) > gap_thr)[0]
+        starts, ends = [0] + (gaps + 1).tolist(), gaps.tolist() + [len(ts) - 1]
+        for s, e in zip(starts, ends):
+            seg_len = e - s + 1
+            if seg_len < 2:
+                continue
+            st, sp = ts[s:e + 1], ps[s:e + 1]
+            if not np.all(np.diff(st) > 1e-9):
+                continue
+            try:
+                fn = interp1d(st, sp, axis=0, kind="cubic" if seg_len >= 4 else "linear", bounds_error=False, fill_value=np.nan)
+            except ValueError:
+                continue
+            idx = np.where((slam_times >= st[0] - 1e-9) & (slam_times <= st[-1] + 1e-9))[0]
+            if len(idx) > 0:
+                vals = fn(slam_times[idx])
+                aligned[idx] = vals
+                valid[idx[~np.isnan(vals).any(axis=1)]] = True
+        return aligned, valid
+    except ValueError:
+        return np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
+
+
+# ---------------------------------------------------------------------------- Sim3 (EKFGPSSLAM.py:389-467)
+def compute_sim3_transform(src, dst):
+    """Umeyama fit dst ~ s R src + t -> (R(3,3), t(3,), scale) or (None, None, None) (ref :428-459).  K2 on the GPU."""
+    src, dst = np.asarray(src, dtype=np.float64), np.asarray(dst, dtype=np.float64)
+    n_points = src.shape[0]
+    if n_points < 3:
+        return None, None, None
+    if src.shape != dst.shape or src.ndim != 2 or src.shape[1] != 3:
+        return None, None, None
+    src, dst = np.ascontiguousarray(src), np.ascontiguousarray(dst)
+    off = np.array([0, n_points], dtype=np.int64)
+    R, t, s, st = np.empty((1, 9)), np.empty((1, 3)), np.empty(1), np.zeros(1, dtype=np.int32)
+    check(_lib.load().gsf_sim3_umeyama_batch(_ctx().handle, hptr(src), hptr(dst), None, hptr(off), 1, hptr(R), hptr(t), hptr(s), hptr(st)))
+    if st[0] == _lib.SIM3_NONE:
+        return None, None, None
+    return R.reshape(3, 3), t.reshape(3), float(s[0])
+
+
+def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max_trials, min_inliers_needed, point_description="pts"):
+    """RANSAC-wrapped Sim3 (ref :389-426).  The sample indices are drawn here with the reference's own RNG call
+    (np.random.choice(n, min_samples, replace=False) per trial, legacy global stream, ref :405); hypothesis
+    fitting, scoring, arg-max and the final inlier fit run in one K2b launch."""
+    src, dst = np.asarray(src, dtype=np.float64), np.asarray(dst, dtype=np.float64)
+    n_points = src.shape[0]
+    if n_points < min_samples:
+        return None, None, None
+    if src.shape != dst.shape:
+        return None, None, None
+    if not 1 <= int(min_samples) <= 8:
+        raise ValueError("min_samples must be in [1, 8] for the device RANSAC")
+    idx = np.empty((int(max_trials), int(min_samples)), dtype=np.int32)
+    for k in range(int(max_trials)):
+        idx[k] = np.random.choice(n_points, min_samples, replace=False)
+    res = sim3_ransac_with_indices(src, dst, idx, residual_threshold, min_inliers_needed)
+    return res[:3]
+
+
+def sim3_ransac_with_indices(src, dst, sample_idx, residual_threshold, min_inliers_needed):
+    """K2b with caller-provided sample indices -> (R, t, s, inlier_mask, n_inliers) or (None, None, None, mask, n)."""
+    src, dst = np.ascontiguousarray(src, dtype=np.float64), np.ascontiguousarray(dst, dtype=np.float64)
+    sample_idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+    n = src.shape[0]
+    trials, ms = sample_idx.shape
+    off = np.array([0, n], dtype=np.int64)
+    R, t, s = np.empty((1, 9)), np.empty((1, 3)), np.empty(1)
+    st, nin, mask = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(max(n, 1), dtype=np.uint8)
+    check(_lib.load().gsf_sim3_ransac_batch(_ctx().handle, hptr(src), hptr(dst), hptr(off), 1, hptr(sample_idx), trials, ms,
+                                            float(residual_threshold), int(min_inliers_needed), hptr(R), hptr(t), hptr(s), hptr(st),
+                                            hptr(mask), hptr(nin)))
+    mask = mask[:n].astype(bool)
+    if st[0] == _lib.SIM3_NONE:
+        return None, None, None, mask, int(nin[0])
+    return R.reshape(3, 3), t.reshape(3), float(s[0]), mask, int(nin[0])
+
+
+def transform_trajectory(positions, quaternions, R_mat, t_vec, scale_val):
+    """Apply a Sim3 to positions and orientations (ref :461-467).  K3 on the GPU."""
+    pos, quat = np.ascontiguousarray(positions, dtype=np.float64), np.ascontiguousarray(quaternions, dtype=np.float64)
+    n = pos.shape[0]
+    if quat.shape != (n, 4) or pos.shape != (n, 3):
+        raise ValueError("positions must be (N,3) and quaternions (N,4)")
+    off = np.array([0, n], dtype=np.int64)
+    R = np.ascontiguousarray(R_mat, dtype=np.float64).reshape(1, 9)
+    t = np.ascontiguousarray(t_vec, dtype=np.float64).reshape(1, 3)
+    s = np.array([float(scale_val)])
+    po, qo, bad = np.empty_like(pos), np.empty_like(quat), np.zeros(1, dtype=np.int32)
+    check(_lib.load().gsf_apply_sim3_batch(_ctx().handle, hptr(pos), hptr(quat), hptr(off), 1, hptr(R), hptr(t), hptr(s), hptr(po), hptr(qo), hptr(bad)))
+    if bad[0]:
+        raise ValueError("Found zero norm quaternions in `quat`.")       # what SciPy raises at ref :466
+    return po, qo
+
+
+# ---------------------------------------------------------------------------- EKF + RTS (EKFGPSSLAM.py:831-935)
+def apply_ekf_correction(slam_data_in, gps_data_in, sim3_pos_initial, sim3_quat_initial, global_config):
+    """EKF + dynamic per-outage RTS fusion of one trajectory -> (pos (N,3), quat (N,4)) (ref :831-935).
+    ValueError on length mismatch (ref :836-837).  The recursion runs in one K4 launch."""
+    n_points = len(slam_data_in["timestamps"])
+    if n_points == 0:
+        return np.empty((0, 3)), np.empty((0, 4))
+    sim3_pos_initial, sim3_quat_initial = np.asarray(sim3_pos_initial), np.asarray(sim3_quat_initial)
+    if not (sim3_pos_initial.shape[0] == n_points and sim3_quat_initial.shape[0] == n_points):
+        raise ValueError(f"Sim3-transformed trajectory length ({sim3_pos_initial.shape[0]}) != SLAM timestamp count ({n_points})")
+    aligned, valid = dynamic_time_alignment(slam_data_in, gps_data_in, global_config["time_alignment"])     # ref :847
+    return ekf_fuse_aligned(slam_data_in["timestamps"], slam_data_in["positions"], slam_data_in["quaternions"], aligned, valid,
+                            sim3_pos_initial[0], sim3_quat_initial[0], global_config)[:2]
+
+
+def ekf_fuse_aligned(timestamps, positions, quaternions, aligned_gps, valid_mask, init_pos, init_quat, global_config=None):
+    """ref :831-935 after its alignment call: one trajectory, host arrays -> (pos, quat, status bits)."""
+    cfg = EkfConfig.from_config(global_config or CONFIG)
+    ts = f64(timestamps).ravel()
+    n = ts.size
+    pos, quat, gps = f64(positions, (n, 3)), f64(quaternions, (n, 4)), f64(aligned_gps, (n, 3))
+    valid = np.ascontiguousarray(valid_mask, dtype=np.uint8).reshape(n)
+    ip, iq = f64(init_pos, (1, 3)), f64(init_quat, (1, 4))
+    po, qo, st = np.empty((n, 3)), np.empty((n, 4)), np.zeros(1, dtype=np.int32)
+    check(_lib.load().gsf_ekf_fuse_batch(_ctx().handle, _lib.LAYOUT_TRAJ_MAJOR, hptr(ts), hptr(pos), hptr(quat), hptr(gps), hptr(valid),
+                                         hptr(ip), hptr(iq), C.byref(cfg), 1, n, hptr(po), hptr(qo), hptr(st)))
+    return po, qo, int(st[0])
+
+
+# ---------------------------------------------------------------------------- headless driver (EKFGPSSLAM.py:940-1104, no GUI)
+def pick_sim3_indices(slam_data, valid_mask, config=None):
+    """Which time-synchronised points feed the global Sim3 (first gap-free segment, <= max_initial_duration) -- ref :973-998."""
+    config = config or CONFIG
+    vi = np.where(valid_mask)[0]
+    ms = config["sim3_ransac"]["min_samples"]
+    if len(vi) < ms:
+        raise ValueError(f"time-synchronised points for Sim3 ({len(vi)}) < RANSAC min_samples ({ms})")
+    vt = slam_data["timestamps"][vi]
+    gaps = np.where(np.diff(vt) > config["time_alignment"]["max_gps_gap_threshold"])[0]
+    end = gaps[0] if len(gaps) > 0 else len(vi)
+    first = vi[:end]
+    if len(first) < ms:
+        return vi
+    lim = slam_data["timestamps"][first] <= slam_data["timestamps"][first[0]] + config["sim3_ransac"]["max_initial_duration"]
+    timed = first[lim]
+    return first if len(timed) < ms else timed
+
+
+def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):
+    """Steps 1-5 (+7: save) of main_process_gui without tk dialogs (ref :940-1104).  Returns a dict of all stages."""
+    config = copy.deepcopy(config or CONFIG)
+    slam = load_slam_trajectory(slam_path)                                                       # step 1
+    gps = load_gps_data(gps_path, data_label="primary GPS", filter_config_override=config["gps_filtering_ransac"])
+    if len(slam["positions"]) == 0 or len(gps["positions"]) < 2:
+        raise ValueError("empty SLAM data or fewer than 2 GPS points")
+    aligned, valid = dynamic_time_alignment(slam, gps, config["time_alignment"])                 # step 2
+    idx = pick_sim3_indices(slam, valid, config)
+    sc = config["sim3_ransac"]
+    R, t, s = compute_sim3_transform_robust(slam["positions"][idx], aligned[idx], sc["min_samples"], sc["residual_threshold"],
+                                            sc["max_trials"], sc["min_inliers_needed"])          # step 3
+    if R is None:
+        raise RuntimeError("global Sim3 transform failed")                                       # ref :1003
+    sim3_pos, sim3_quat = transform_trajectory(slam["positions"], slam["quaternions"], R, t, s)  # step 4
+    pos, quat = apply_ekf_correction(slam, gps, sim3_pos, sim3_quat, config)                     # step 5
+    if out_path_utm:                                                                             # step 7
+        save_tum_utm(out_path_utm, slam["timestamps"], pos, quat)
+        wgs = utm_to_wgs84(pos, gps["projector"])
+        out_wgs = out_path_utm.replace("_utm.txt", "_wgs84.txt")
+        if out_wgs == out_path_utm:
+            out_wgs = out_path_utm.replace(".txt", "_wgs84.txt") if ".txt" in out_path_utm else out_path_utm + "_wgs84.txt"
+        save_tum_wgs84(out_wgs, slam["timestamps"], wgs, quat)
+    return {"slam": slam, "gps": gps, "aligned": aligned, "valid": valid, "sim3_idx": idx, "R": R, "t": t, "s": s,
+            "sim3_pos": sim3_pos, "sim3_quat": sim3_quat, "pos": pos, "quat": quat}

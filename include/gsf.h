@@ -1,0 +1,183 @@
+/*
+ * gsf.h -- C ABI of libgsf.so: the MI355X (gfx950) GPS<->SLAM trajectory-fusion hot path.
+ *
+ * The reference (A2ureeE/GPS-optimize-SLAM) has no FFI: its hot path sits behind
+ * module-level Python functions of EKFGPSSLAM.py.  Each entry point below names the
+ * reference function (file:line) whose arithmetic it replaces; the Python module
+ * gps_optimize_slam_amd.ekfgpsslam binds them with ctypes and re-exports the reference's
+ * own function names (INTEGRATION.md shows the stub a maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is caller-owned, the library never
+ *     retains or frees it.  All floating point is IEEE float64.  Quaternions are
+ *     scalar-last [x,y,z,w] (SciPy convention, as in the reference's TUM files).
+ *   - `*_dev` entry points take DEVICE pointers and are asynchronous on the context's
+ *     HIP stream; the matching host-pointer entry points copy in/out and synchronise.
+ *   - return value: 0 = GSF_OK, otherwise a gsf_error; gsf_last_error() gives the
+ *     thread-local message.  Per-item results (the reference's `None` returns, outage
+ *     bookkeeping) come back in `status` arrays, never as failures of the call.
+ *   - there is NO CPU fallback: without a HIP device gsf_create fails.
+ */
+#ifndef GSF_H
+#define GSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSF_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define GSF_API __attribute__((visibility("default")))
+#else
+#define GSF_API
+#endif
+
+typedef enum {
+    GSF_OK = 0,
+    GSF_ERR_INVALID_ARG = 1,
+    GSF_ERR_HIP = 2,
+    GSF_ERR_NO_DEVICE = 3,
+    GSF_ERR_UNSUPPORTED = 4
+} gsf_error;
+
+/* batch memory layouts of the fusion kernels */
+typedef enum {
+    /* trajectory-major AoS (what B stacked TUM files look like):
+       ts[B][N] pos[B][N][3] quat[B][N][4] gps[B][N][3] valid[B][N], outputs alike */
+    GSF_LAYOUT_TRAJ_MAJOR = 0,
+    /* time-major SoA (trajectory index fastest: every wave access is one contiguous 512-B row):
+       ts[N][B] pos[N][3][B] quat[N][4][B] gps[N][3][B] valid[N][B], outputs alike */
+    GSF_LAYOUT_TIME_MAJOR = 1
+} gsf_layout;
+
+/* CONFIG['ekf'] + CONFIG['rts_decision'] of the reference (EKFGPSSLAM.py:24-29, :67-70) */
+typedef struct {
+    double initial_cov_diag[7];        /* :25 */
+    double process_noise_diag[7];      /* :26  per second, used as variances */
+    double meas_noise_diag[3];         /* :27  used as variances (Q4) */
+    double sharp_turn_yaw_rate_threshold_deg_per_sec;   /* :68 */
+    int32_t default_ekf_transition_steps_on_sharp_turn; /* :69 */
+    int32_t reserved;
+} gsf_ekf_config;
+
+/* status of a Sim3 fit: GSF_SIM3_NONE <=> the reference returned (None, None, None) */
+#define GSF_SIM3_OK 0
+#define GSF_SIM3_NONE 1
+#define GSF_SIM3_FLAG_VAR0 2          /* var_src < 1e-12 -> scale := 1   (EKFGPSSLAM.py:445-447) */
+#define GSF_SIM3_FLAG_SMALL_SCALE 4   /* scale <= 1e-6  -> scale := 1   (EKFGPSSLAM.py:450) */
+
+/* status bits of a fused trajectory */
+#define GSF_ST_HAD_OUTAGE 1
+#define GSF_ST_RTS_APPLIED 2
+#define GSF_ST_SHARP_TURN 4
+#define GSF_ST_ENDED_IN_OUTAGE 8
+#define GSF_ST_BAD_QUAT 16            /* a zero/NaN SLAM quaternion took the zero-motion branch (:84-86) */
+
+typedef struct gsf_ctx gsf_ctx;       /* opaque: device id + HIP stream + scratch */
+
+/* ---- context ------------------------------------------------------------------------- */
+GSF_API const char *gsf_version(void);
+GSF_API int gsf_abi_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+GSF_API int gsf_last_error(char *buf, int n);
+/* number of HIP devices visible (0 if none / no driver) */
+GSF_API int gsf_device_count(void);
+/* creates a context on `device_id` with its own non-blocking stream */
+GSF_API int gsf_create(int device_id, gsf_ctx **out);
+/* same, but launches on a caller-owned hipStream_t (e.g. torch's current stream); not destroyed by gsf_destroy */
+GSF_API int gsf_create_on_stream(int device_id, void *hip_stream, gsf_ctx **out);
+GSF_API void gsf_destroy(gsf_ctx *ctx);
+GSF_API int gsf_synchronize(gsf_ctx *ctx);
+/* tuning knobs; keys: "ekf_variant" (0 default; prefetch-depth/occupancy variants of K4) */
+GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
+/* opens / closes a HIP-event bracket on the context's stream; gsf_timer_stop returns the elapsed ms */
+GSF_API int gsf_timer_start(gsf_ctx *ctx);
+GSF_API int gsf_timer_stop(gsf_ctx *ctx, float *elapsed_ms);
+
+/* ---- K1: WGS84 -> UTM  (replaces pyproj Proj(...)(lons, lats), EKFGPSSLAM.py:266-271) ------ */
+/* zone/hemisphere pick of auto_utm_projection (EKFGPSSLAM.py:127-134), one per trajectory:
+   zone = int((mean(lon)+180)//6+1), south = mean(lat) < 0.  offsets: int64[B+1] into lat/lon. */
+GSF_API int gsf_utm_zone_batch_dev(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const int64_t *offsets,
+                           int64_t B, int32_t *zone, int32_t *south);
+/* forward projection of B ragged trajectories, each in its own zone; invalid input rows
+   (EKFGPSSLAM.py:259: |lat|>90, |lon|>180, lat==0, lon==0) produce NaN */
+GSF_API int gsf_utm_forward_batch_dev(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const int64_t *offsets,
+                              const int32_t *zone, const int32_t *south, int64_t B, double *easting, double *northing);
+/* inverse projection (utm_to_wgs84, EKFGPSSLAM.py:291-296) */
+GSF_API int gsf_utm_inverse_batch_dev(gsf_ctx *ctx, const double *easting, const double *northing, const int64_t *offsets,
+                              const int32_t *zone, const int32_t *south, int64_t B, double *lat_deg, double *lon_deg);
+/* host-pointer, single-zone convenience forms used by the drop-in load_gps_data / utm_to_wgs84 */
+GSF_API int gsf_utm_forward(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, int64_t n, int32_t zone, int32_t south,
+                    double *easting, double *northing);
+GSF_API int gsf_utm_inverse(gsf_ctx *ctx, const double *easting, const double *northing, int64_t n, int32_t zone, int32_t south,
+                    double *lat_deg, double *lon_deg);
+
+/* ---- K2: Sim3 / Umeyama (compute_sim3_transform, EKFGPSSLAM.py:428-459) ------------------- */
+/* B ragged point sets: src/dst are [total][3]; offsets int64[B+1].  Optional `mask` (uint8[total], may be NULL)
+   selects the rows that take part (used for "valid GNSS only" fits).  Outputs R[B][9] (row-major), t[B][3],
+   s[B], status[B]. */
+GSF_API int gsf_sim3_umeyama_batch_dev(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask,
+                               const int64_t *offsets, int64_t B, double *R, double *t, double *s, int32_t *status);
+GSF_API int gsf_sim3_umeyama_batch(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask,
+                           const int64_t *offsets, int64_t B, double *R, double *t, double *s, int32_t *status);
+
+/* ---- K2b: RANSAC wrapper (compute_sim3_transform_robust, EKFGPSSLAM.py:389-426) ------------ */
+/* sample_idx: int32[B][trials][min_samples], drawn BY THE HOST with the reference's RNG call
+   (np.random.choice(n, min_samples, replace=False), :405) so results are reproducible against it.
+   inlier_mask: uint8[total] out; n_inliers: int32[B] out (best count, -1 if no trial succeeded). */
+GSF_API int gsf_sim3_ransac_batch_dev(gsf_ctx *ctx, const double *src, const double *dst, const int64_t *offsets, int64_t B,
+                              const int32_t *sample_idx, int32_t trials, int32_t min_samples, double residual_threshold,
+                              int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,
+                              uint8_t *inlier_mask, int32_t *n_inliers);
+GSF_API int gsf_sim3_ransac_batch(gsf_ctx *ctx, const double *src, const double *dst, const int64_t *offsets, int64_t B,
+                          const int32_t *sample_idx, int32_t trials, int32_t min_samples, double residual_threshold,
+                          int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,
+                          uint8_t *inlier_mask, int32_t *n_inliers);
+
+/* ---- K3: apply Sim3 (transform_trajectory, EKFGPSSLAM.py:461-467) -------------------------- */
+/* pos[total][3], quat[total][4]; per-trajectory R[B][9], t[B][3], s[B].  A zero-norm quaternion (SciPy raises
+   ValueError there) yields NaN quaternion output and sets bad_quat[b] (int32[B], may be NULL). */
+GSF_API int gsf_apply_sim3_batch_dev(gsf_ctx *ctx, const double *pos, const double *quat, const int64_t *offsets, int64_t B,
+                             const double *R, const double *t, const double *s, double *pos_out, double *quat_out,
+                             int32_t *bad_quat);
+GSF_API int gsf_apply_sim3_batch(gsf_ctx *ctx, const double *pos, const double *quat, const int64_t *offsets, int64_t B,
+                         const double *R, const double *t, const double *s, double *pos_out, double *quat_out,
+                         int32_t *bad_quat);
+
+/* ---- K4: EKF + per-outage RTS (apply_ekf_correction, EKFGPSSLAM.py:831-935, after its :847 alignment) -- */
+/* B trajectories of N poses each.  ts/pos/quat = ORIGINAL SLAM track, gps/valid = GNSS time-aligned to the SLAM
+   stamps (NaN allowed), init_pos[B][3]/init_quat[B][4] = row 0 of the Sim3-aligned track.
+   Outputs pos_out/quat_out in the same layout, status[B] (GSF_ST_* bits). */
+GSF_API int gsf_ekf_fuse_batch_dev(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
+                           const double *gps, const uint8_t *valid, const double *init_pos, const double *init_quat,
+                           const gsf_ekf_config *cfg, int64_t B, int64_t N, double *pos_out, double *quat_out,
+                           int32_t *status);
+GSF_API int gsf_ekf_fuse_batch(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
+                       const double *gps, const uint8_t *valid, const double *init_pos, const double *init_quat,
+                       const gsf_ekf_config *cfg, int64_t B, int64_t N, double *pos_out, double *quat_out,
+                       int32_t *status);
+
+/* ---- fused pipeline: Umeyama on the valid rows -> Sim3 of pose 0 -> EKF+RTS, one launch chain --------- */
+/* (steps 3-5 of main_process_gui, EKFGPSSLAM.py:1002-1010, with the plain fit of :428 instead of RANSAC).
+   Trajectories whose fit is None get status GSF_ST_* | (GSF_SIM3_NONE << 8) and NaN outputs. */
+GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
+                                const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
+                                double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
+
+/* ---- layout helpers + synthetic workload (bench / tests) ------------------------------------------ */
+/* [B][N][C] <-> [N][C][B] transposes of float64 (C = 1,3,4) and uint8 (C = 1) arrays, on device */
+GSF_API int gsf_transpose_to_time_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);
+GSF_API int gsf_transpose_to_traj_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);
+/* deterministic KITTI-04-shaped synthetic batch, generated on device straight into `layout`;
+   trajectory ids [traj0, traj0+B).  Integer counter-based RNG + polynomial curves only: the host generator in
+   gps_optimize_slam_amd/synth.py produces bit-identical values. */
+GSF_API int gsf_synth_batch_dev(gsf_ctx *ctx, int32_t layout, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double *ts,
+                        double *pos, double *quat, double *gps, uint8_t *valid, double *init_pos, double *init_quat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSF_H */

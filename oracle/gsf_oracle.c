@@ -792,6 +792,48 @@ ORC_API void orc_fuse_batch(const double *ts, const double *pos, const double *q
     }
 }
 
+
+/* Steps 3-5 of main_process_gui (ref :1002-1010) with the plain fit of :428 for B equal-length trajectories:
+ * compute_sim3_transform on the rows with valid, non-NaN GNSS -> transform_trajectory (only row 0 is consumed,
+ * SURVEY Q3) -> apply_ekf_correction.  status = ekf bits | (sim3 status << 8); a None fit leaves NaN outputs. */
+ORC_API void orc_fuse_pipeline_batch(const double *ts, const double *pos, const double *quat, const double *aligned,
+                                     const uint8_t *valid, int64_t B, int64_t n, const orc_config *cfg, double *Rout,
+                                     double *tout, double *sout, double *pos_out, double *quat_out, int32_t *status)
+{
+    double *src = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    double *dst = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    for (int64_t b = 0; b < B; ++b) {
+        const double *p = pos + b * n * 3, *z = aligned + b * n * 3, *q = quat + b * n * 4;
+        const uint8_t *v = valid + b * n;
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (!v[i] || isnan(z[i * 3]) || isnan(z[i * 3 + 1]) || isnan(z[i * 3 + 2])) continue;
+            for (int c = 0; c < 3; ++c) { src[m * 3 + c] = p[i * 3 + c]; dst[m * 3 + c] = z[i * 3 + c]; }
+            ++m;
+        }
+        double R[9], t[3], s = NAN;
+        int fit = orc_umeyama(src, dst, m, R, t, &s);
+        double p0[3], q0[4];
+        int bad = 1;
+        if (fit != ORC_SIM3_NONE && n > 0) bad = orc_transform_trajectory(p, q, 1, R, t, s, p0, q0);
+        if (fit == ORC_SIM3_NONE || bad) {
+            for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
+            for (int k = 0; k < 3; ++k) tout[b * 3 + k] = NAN;
+            sout[b] = NAN;
+            for (int64_t i = 0; i < n * 3; ++i) pos_out[b * n * 3 + i] = NAN;
+            for (int64_t i = 0; i < n * 4; ++i) quat_out[b * n * 4 + i] = NAN;
+            if (status) status[b] = (fit == ORC_SIM3_NONE ? (ORC_SIM3_NONE << 8) : 0) | (bad && fit != ORC_SIM3_NONE ? ORC_ST_BAD_QUAT : 0);
+            continue;
+        }
+        for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = R[k];
+        for (int k = 0; k < 3; ++k) tout[b * 3 + k] = t[k];
+        sout[b] = s;
+        int st = orc_apply_ekf_correction(ts + b * n, p, q, z, v, n, p0, q0, cfg, pos_out + b * n * 3, quat_out + b * n * 4);
+        if (status) status[b] = st | (fit << 8);
+    }
+    free(src); free(dst);
+}
+
 /* ------------------------------------------------------------------------ */
 /* time alignment  (ref :301-387)  -- "next-1" row of SURVEY 8(f)            */
 /* ------------------------------------------------------------------------ */

@@ -104,6 +104,9 @@ def lib():
         L.orc_fuse_batch.restype = None
         L.orc_fuse_batch.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, C.c_int64, f64p, f64p,
                                      C.POINTER(OrcConfig), f64p, f64p, i32p]
+        L.orc_fuse_pipeline_batch.restype = None
+        L.orc_fuse_pipeline_batch.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, C.c_int64, C.POINTER(OrcConfig),
+                                              f64p, f64p, f64p, f64p, f64p, i32p]
         L.orc_estimate_time_offset.restype = C.c_double
         L.orc_estimate_time_offset.argtypes = [f64p, C.c_int64, f64p, C.c_int64, C.c_int]
         L.orc_dynamic_time_alignment.restype = None
@@ -263,6 +266,19 @@ def fuse_batch(ts, pos, quat, aligned, valid, init_pos, init_quat, cfg=None):
     c = OrcConfig.from_dict(cfg)
     lib().orc_fuse_batch(ts, pos, quat, aligned, valid, B, n, _a(init_pos), _a(init_quat), C.byref(c), po, qo, st)
     return po, qo, st
+
+
+def fuse_pipeline_batch(ts, pos, quat, aligned, valid, cfg=None):
+    """Umeyama(valid rows) -> Sim3 of pose 0 -> EKF+RTS for B equal-length trajectories (trajectory-major AoS).
+    Returns pos (B,n,3), quat (B,n,4), status (B,), R (B,9), t (B,3), s (B,)."""
+    ts, pos, quat, aligned = _a(ts), _a(pos), _a(quat), _a(aligned)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    B, n = ts.shape
+    po, qo = np.empty((B, n, 3)), np.empty((B, n, 4))
+    R, t, s, st = np.empty((B, 9)), np.empty((B, 3)), np.empty(B), np.zeros(B, dtype=np.int32)
+    c = OrcConfig.from_dict(cfg)
+    lib().orc_fuse_pipeline_batch(ts, pos, quat, aligned, valid, B, n, C.byref(c), R, t, s, po, qo, st)
+    return po, qo, st, R, t, s
 
 
 def dynamic_time_alignment(slam_t, gps_t, gps_p, max_samples=500, max_gap=5.0):

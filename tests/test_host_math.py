@@ -1,0 +1,111 @@
+"""CPU-tier check of the PRODUCT's per-lane math (gps_optimize_slam_amd/csrc/*.hpp): the headers
+the HIP kernels inline are compiled with g++ into a test-only harness (tests/host_harness.cpp) and
+compared with the oracle / goldens.  The kernels themselves (indexing, launches) are covered by the
+-m gpu tests."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class EkfConfig(C.Structure):
+    _fields_ = [("P0", C.c_double * 7), ("Qps", C.c_double * 7), ("Rm", C.c_double * 3), ("yaw_thr_rad", C.c_double),
+                ("sharp_turn_steps", C.c_int32), ("_pad", C.c_int32)]
+
+
+def make_cfg(cfg):
+    c = EkfConfig()
+    c.P0[:] = cfg["ekf"]["initial_cov_diag"]; c.Qps[:] = cfg["ekf"]["process_noise_diag"]
+    c.Rm[:] = cfg["ekf"]["meas_noise_diag"]
+    c.yaw_thr_rad = float(np.deg2rad(cfg["rts_decision"]["sharp_turn_yaw_rate_threshold_deg_per_sec"]))
+    c.sharp_turn_steps = int(cfg["rts_decision"]["default_ekf_transition_steps_on_sharp_turn"])
+    return c
+
+
+@pytest.fixture(scope="module")
+def hh():
+    bdir = os.path.join(HERE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, "libhost_harness.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_harness.cpp")])
+    L = C.CDLL(so)
+    assert L.hh_ekf_config_size() == C.sizeof(EkfConfig)
+    L.hh_ekf_fuse.restype = C.c_int
+    L.hh_ekf_fuse.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, f64p, f64p, C.POINTER(EkfConfig), f64p, f64p]
+    L.hh_umeyama.restype = C.c_int
+    L.hh_umeyama.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.POINTER(C.c_double)]
+    L.hh_utm_forward.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+    L.hh_utm_inverse.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+    return L
+
+
+def _fuse(hh, ts, pos, quat, al, va, p0, q0, cfg):
+    n = len(ts)
+    po, qo = np.empty((n, 3)), np.empty((n, 4))
+    c = make_cfg(cfg)
+    a = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    st = hh.hh_ekf_fuse(a(ts), a(pos), a(quat), a(al), np.ascontiguousarray(va, dtype=np.uint8), n, a(p0), a(q0), C.byref(c), po, qo)
+    return po, qo, st
+
+
+def test_ekf_core_vs_goldens(hh, golden):
+    import copy
+    g = golden("ekf_cases.npz")
+    for name in g["names"]:
+        cfg = copy.deepcopy(orc.DEFAULT_CONFIG)
+        for sec, kv in json.loads(str(g[f"{name}_cfg"])).items():
+            cfg[sec].update(kv)
+        args = (g[f"{name}_ts"], g[f"{name}_pos"], g[f"{name}_quat"], g[f"{name}_aligned"], g[f"{name}_valid"], g[f"{name}_sp0"], g[f"{name}_sq0"])
+        p, q, st = _fuse(hh, *args, cfg)
+        # gate of the product: 1e-6 m; the diagonal/register formulation actually lands ~1e-9
+        np.testing.assert_allclose(p, g[f"{name}_out_pos"], atol=2e-8, rtol=0, err_msg=str(name))
+        np.testing.assert_allclose(q, g[f"{name}_out_quat"], atol=1e-12, rtol=0, err_msg=str(name))
+        _, _, st_o = orc.apply_ekf_correction_aligned(*args, cfg, return_status=True)
+        assert st == st_o, (name, st, st_o)
+
+
+@pytest.mark.parametrize("kat", ["kat3", "kat4"])
+def test_ekf_core_bundled(hh, golden, kat):
+    g = golden("kat_bundled.npz")
+    p, q, st = _fuse(hh, g["ts"], g["pos"], g["quat"], g[f"{kat}_aligned"], g[f"{kat}_valid"], g["kat2_pos"][0], g["kat2_quat"][0], orc.DEFAULT_CONFIG)
+    np.testing.assert_allclose(p, g[f"{kat}_pos"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(q, g[f"{kat}_quat"], atol=1e-12, rtol=0)
+
+
+def test_umeyama_core(hh, golden):
+    g = golden("sim3_cases.npz")
+    for name in g["names"]:
+        src, dst = np.ascontiguousarray(g[f"{name}_src"]), np.ascontiguousarray(g[f"{name}_dst"])
+        R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+        rc = hh.hh_umeyama(src.reshape(-1, 3), dst.reshape(-1, 3), src.shape[0], R, t, C.byref(s))
+        Ro, to, so, fo = orc.compute_sim3_transform(src, dst, return_flags=True)
+        assert rc == fo, name
+        if rc == 1:
+            continue
+        if name in ("planar", "zerovar"):
+            np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+            assert abs(s.value - so) < 1e-12
+            continue
+        np.testing.assert_allclose(R, g[f"{name}_R"], atol=1e-12, rtol=0, err_msg=str(name))
+        np.testing.assert_allclose(t, g[f"{name}_t"], atol=1e-8, rtol=0, err_msg=str(name))
+        assert abs(s.value - float(g[f"{name}_s"])) < 1e-12
+
+
+def test_utm_core(hh, golden):
+    g = golden("utm_mpmath.npz")
+    for la, lo, z, s, E, N in zip(g["lat"], g["lon"], g["zone"], g["south"], g["E"], g["N"]):
+        e, n = np.empty(1), np.empty(1)
+        hh.hh_utm_forward(np.array([la]), np.array([lo]), 1, int(z), int(s), e, n)
+        assert abs(e[0] - E) < 4e-9 and abs(n[0] - N) < 4e-9, (la, lo, e[0] - E, n[0] - N)
+        la2, lo2 = np.empty(1), np.empty(1)
+        hh.hh_utm_inverse(e, n, 1, int(z), int(s), la2, lo2)
+        assert abs(la2[0] - la) < 1e-12 and abs(lo2[0] - lo) < 1e-12
