@@ -89,14 +89,39 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, same as /opt/rocm's).  Two HIP
+    runtimes in one process each see 0 devices once the other owns the KFD queue, so when torch is installed its copy is
+    mapped FIRST (without importing torch); libgsf.so's DT_NEEDED then binds to it by soname and the process has a single
+    runtime whichever of torch / libgsf is touched first.  Without torch, libgsf.so uses /opt/rocm's runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+_hip_rt = None
+
+
 def load():
     """dlopen libgsf.so and type every entry point.  Raises GsfError if the library is not built."""
-    global _lib
+    global _lib, _hip_rt
     with _lock:
         if _lib is None:
             if not os.path.exists(_SO):
                 raise GsfError(f"{_SO} is missing: build it with gps_optimize_slam_amd.build_library() "
                                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            _hip_rt = _preload_torch_hip_runtime()
             L = C.CDLL(_SO)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)

@@ -176,6 +176,9 @@ def test_utm_vs_mpmath_definition(E, golden):
     for la, lo, z, s, Ee, Nn in zip(g["lat"], g["lon"], g["zone"], g["south"], g["E"], g["N"]):
         proj = E.UtmProjector(int(z), bool(s))
         e, n = proj(np.array([lo]), np.array([la]))
+        if la == 0.0 or lo == 0.0:            # rows the reference's validity mask drops (ref :259) come back NaN
+            assert np.isnan(e[0]) and np.isnan(n[0])
+            continue
         assert abs(e[0] - Ee) < 5e-9 and abs(n[0] - Nn) < 5e-9, (la, lo, e[0] - Ee, n[0] - Nn)
         lo2, la2 = proj(e, n, inverse=True)
         assert abs(la2[0] - la) < 1e-12 and abs(lo2[0] - lo) < 1e-12
@@ -274,7 +277,7 @@ def test_umeyama_windows_vs_oracle(B, orc):
 def test_utm_batch_zone_pick(B, orc):
     import torch
     rng = np.random.default_rng(9)
-    centers = [(49.03, 8.39), (8.39, 49.03), (-33.9, 18.4), (35.0, -120.0)]
+    centers = [(49.03, 8.39), (8.39, 49.03), (-33.9, 18.4), (35.0, -117.0)]
     lat = np.concatenate([c[0] + rng.uniform(-0.02, 0.02, 300) for c in centers])
     lon = np.concatenate([c[1] + rng.uniform(-0.02, 0.02, 300) for c in centers])
     offs = torch.arange(0, 1201, 300, dtype=torch.int64).cuda()
@@ -299,8 +302,10 @@ def test_full_size_properties(B):
     p_first = out.pos[0].clone()            # (3, B)
     torch.cuda.synchronize()
     q0 = batch.init_quat / batch.init_quat.norm(dim=1, keepdim=True)
-    assert torch.equal(p_first.T.contiguous(), batch.init_pos)
-    assert (out.quat[0].T - q0).abs().max().item() < 1e-15
+    keep = batch.valid[0] != 0              # a track that STARTS in an outage has row 0 rewritten by the RTS pass (Q11)
+    assert torch.equal(p_first.T.contiguous()[keep], batch.init_pos[keep])
+    assert (out.quat[0].T - q0)[keep].abs().max().item() < 1e-15
+    assert 0.005 < (~keep).float().mean().item() < 0.05
     out2 = B.ekf_fuse_batch(batch)
     torch.cuda.synchronize()
     assert torch.equal(out.pos, out2.pos) and torch.equal(out.quat, out2.quat)
