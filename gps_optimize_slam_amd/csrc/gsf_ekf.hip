@@ -32,7 +32,9 @@ struct LaneIO {
     template <typename T>
     __device__ __forceinline__ T* at(T* base, int64_t i, int c, int C) const
     {
-        if (LAYOUT == GSF_LAYOUT_TIME_MAJOR) return (base + (i * C + c) * B) + b;
+        // uniform 64-bit row base (SGPRs) + 32-bit zero-extended lane BYTE offset -> `global_load v, v_off, s[base]` addressing
+        if (LAYOUT == GSF_LAYOUT_TIME_MAJOR)
+            return (T*)((const char*)(base + (i * C + c) * B) + (uint32_t)((uint32_t)b * (uint32_t)sizeof(T)));
         return base + ((b * N + i) * C + c);
     }
     __device__ __forceinline__ StepIn load_step(int64_t i) const

@@ -27,13 +27,39 @@ struct Vec3 { double x, y, z; };
 
 GSF_HD double sq(double a) { return a * a; }
 
+// 1/a and 1/sqrt(a) for normal, positive-magnitude a.  On the device: the hardware seed (v_rcp_f64 / v_rsq_f64) plus two
+// Newton steps in FMA form -- ~5 / ~8 instructions and <= 1 ulp, instead of the ~12 / ~25-instruction IEEE expansions with
+// their div_scale/div_fixup denormal handling (the operands here are |q|^2 ~ 1 and variances ~ 0.1: never denormal).
+GSF_HD double fast_rcp(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0); x = fma(x, e, x);
+    e = fma(-a, x, 1.0); x = fma(x, e, x);
+    return x;
+#else
+    return 1.0 / a;
+#endif
+}
+GSF_HD double fast_rsqrt(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5); g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5); h = fma(h, r, h);
+    return h + h;
+#else
+    return 1.0 / sqrt(a);
+#endif
+}
+
 // Rotation.from_quat: q/|q|; false if the norm is 0/NaN/inf (SciPy raises ValueError).
 GSF_HD bool quat_unit(const Quat& q, Quat& o)
 {
     double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    double n = sqrt(n2);
-    bool ok = (n > 0.0) && (n < INFINITY);
-    double r = 1.0 / n;
+    bool ok = (n2 >= 1e-280) && (n2 <= 1e280);     // sqrt(n2) > 0 and finite; the margins keep fast_rsqrt in its normal range
+    double r = fast_rsqrt(ok ? n2 : 1.0);
     o.x = q.x * r; o.y = q.y * r; o.z = q.z * r; o.w = q.w * r;
     return ok;
 }
@@ -51,12 +77,12 @@ GSF_HD Quat quat_mul(const Quat& p, const Quat& q)
 // Rotation.apply for a unit quaternion: as_matrix() @ v
 GSF_HD Vec3 quat_rotate(const Quat& q, const Vec3& v)
 {
-    double x2 = q.x * q.x, y2 = q.y * q.y, z2 = q.z * q.z, w2 = q.w * q.w;
-    double xy = q.x * q.y, zw = q.z * q.w, xz = q.x * q.z, yw = q.y * q.w, yz = q.y * q.z, xw = q.x * q.w;
+    // M(q) v for a UNIT q in the cross-product form v + w t + u x t, t = 2 u x v (18 flops instead of 39 for the matrix)
+    double tx = 2.0 * (q.y * v.z - q.z * v.y), ty = 2.0 * (q.z * v.x - q.x * v.z), tz = 2.0 * (q.x * v.y - q.y * v.x);
     Vec3 o;
-    o.x = (x2 - y2 - z2 + w2) * v.x + 2.0 * (xy - zw) * v.y + 2.0 * (xz + yw) * v.z;
-    o.y = 2.0 * (xy + zw) * v.x + (-x2 + y2 - z2 + w2) * v.y + 2.0 * (yz - xw) * v.z;
-    o.z = 2.0 * (xz - yw) * v.x + 2.0 * (yz + xw) * v.y + (-x2 - y2 + z2 + w2) * v.z;
+    o.x = v.x + q.w * tx + (q.y * tz - q.z * ty);
+    o.y = v.y + q.w * ty + (q.z * tx - q.x * tz);
+    o.z = v.z + q.w * tz + (q.x * ty - q.y * tx);
     return o;
 }
 // as_euler('zyx')[0] of a unit quaternion: atan2(-m01, m00)
@@ -69,9 +95,10 @@ GSF_HD double quat_yaw_zyx(const Quat& q)
 // ExtendedKalmanFilter.normalize_quaternion, ref :697-700
 GSF_HD Quat ekf_normalize(const Quat& q)
 {
-    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    if (n > 1e-9) { double r = 1.0 / n; return Quat{ q.x * r, q.y * r, q.z * r, q.w * r }; }
-    return Quat{ 0.0, 0.0, 0.0, 1.0 };
+    double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    bool ok = (n2 > 1e-18) && (n2 <= 1e280);       // norm > 1e-9 (ref :699); NaN/inf fall through to the identity like NaN > 1e-9
+    double r = fast_rsqrt(ok ? n2 : 1.0);
+    return ok ? Quat{ q.x * r, q.y * r, q.z * r, q.w * r } : Quat{ 0.0, 0.0, 0.0, 1.0 };
 }
 // quaternion_nlerp, ref :94-105
 GSF_HD Quat quat_nlerp(const Quat& q1, Quat q2, double weight_q2)
