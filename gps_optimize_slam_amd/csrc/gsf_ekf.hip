@@ -44,7 +44,7 @@ struct LaneIO {
         s.p = Vec3{ *at(pos, i, 0, 3), *at(pos, i, 1, 3), *at(pos, i, 2, 3) };
         s.q = Quat{ *at(quat, i, 0, 4), *at(quat, i, 1, 4), *at(quat, i, 2, 4), *at(quat, i, 3, 4) };
         s.z = Vec3{ *at(gps, i, 0, 3), *at(gps, i, 1, 3), *at(gps, i, 2, 3) };
-        s.valid = *at(valid, i, 0, 1) != 0;
+        s.valid = *at(valid, i, 0, 1);
         return s;
     }
     __device__ __forceinline__ void store(int64_t i, const Vec3& p, const Quat& q)
@@ -76,17 +76,23 @@ __global__ __launch_bounds__(64, OCC) void ekf_fuse_kernel(const double* __restr
     const Quat q0{ init_quat[b * 4], init_quat[b * 4 + 1], init_quat[b * 4 + 2], init_quat[b * 4 + 3] };
     EkfTraj<LaneIO<LAYOUT>> f;
     f.init(cfg, p0, q0, io.load_step(0), io);
-    // register ring of the next PF poses: the load for pose i+PF is issued before pose i is consumed
-    StepIn ring[PF];
+    // PF statically-named register buffers (the loop is unrolled PF times, so no rotation moves -- a move would force
+    // a wait on the newest load): the load for pose i+PF is issued right before pose i is consumed, which keeps PF-1
+    // whole steps of compute between a load and its first use.
+    StepIn buf[PF];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) ring[d] = io.load_step((1 + d < N) ? 1 + d : N - 1);
-    for (int64_t i = 1; i < N; ++i) {
-        const StepIn cur = ring[0];
+    for (int d = 0; d < PF; ++d) buf[d] = io.load_step((1 + d < N) ? 1 + d : N - 1);
+    for (int64_t i = 1; i < N; i += PF) {
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d) ring[d] = ring[d + 1];
-        const int64_t nx = i + PF;
-        ring[PF - 1] = io.load_step(nx < N ? nx : N - 1);      // clamped re-read at the tail keeps the loop branch-free
-        f.step(cfg, i, cur, io);
+        for (int d = 0; d < PF; ++d) {
+            const int64_t ii = i + d;
+            if (ii < N) {                                       // wave-uniform
+                const StepIn cur = buf[d];
+                const int64_t nx = ii + PF;
+                buf[d] = io.load_step(nx < N ? nx : N - 1);    // clamped re-read at the tail
+                f.step(cfg, ii, cur, io);
+            }
+        }
     }
     if (status) status[b] = f.finish();
 }
@@ -160,17 +166,23 @@ __global__ __launch_bounds__(64, OCC) void fuse_pipeline_kernel(const double* __
     // ---- pass B
     EkfTraj<LaneIO<LAYOUT>> f;
     f.init(cfg, p0, q0, first, io);
-    // register ring of the next PF poses: the load for pose i+PF is issued before pose i is consumed
-    StepIn ring[PF];
+    // PF statically-named register buffers (the loop is unrolled PF times, so no rotation moves -- a move would force
+    // a wait on the newest load): the load for pose i+PF is issued right before pose i is consumed, which keeps PF-1
+    // whole steps of compute between a load and its first use.
+    StepIn buf[PF];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) ring[d] = io.load_step((1 + d < N) ? 1 + d : N - 1);
-    for (int64_t i = 1; i < N; ++i) {
-        const StepIn cur = ring[0];
+    for (int d = 0; d < PF; ++d) buf[d] = io.load_step((1 + d < N) ? 1 + d : N - 1);
+    for (int64_t i = 1; i < N; i += PF) {
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d) ring[d] = ring[d + 1];
-        const int64_t nx = i + PF;
-        ring[PF - 1] = io.load_step(nx < N ? nx : N - 1);      // clamped re-read at the tail keeps the loop branch-free
-        f.step(cfg, i, cur, io);
+        for (int d = 0; d < PF; ++d) {
+            const int64_t ii = i + d;
+            if (ii < N) {                                       // wave-uniform
+                const StepIn cur = buf[d];
+                const int64_t nx = ii + PF;
+                buf[d] = io.load_step(nx < N ? nx : N - 1);    // clamped re-read at the tail
+                f.step(cfg, ii, cur, io);
+            }
+        }
     }
     if (status) status[b] = f.finish() | (fit << 8);
 }

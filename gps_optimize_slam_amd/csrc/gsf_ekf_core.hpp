@@ -47,7 +47,7 @@ struct StepIn {                    // one pose of the ORIGINAL SLAM track + its 
     Vec3 p;
     Quat q;
     Vec3 z;
-    bool valid;
+    uint32_t valid;               // raw mask byte, compared at USE time (a compare at load time would stall on the newest load)
 };
 
 // (cos, sin) * h of the reference's "yaw" (as_euler('zyx')[0] = atan2(-m01, m00)) of a unit quaternion
@@ -94,7 +94,7 @@ struct EkfTraj {
         p = p0; q = ekf_normalize(q0);                                   // :842, :683
 #pragma unroll
         for (int c = 0; c < 7; ++c) P[c] = cfg.P0[c];
-        prev_avail = first.valid;                                        // :848  (raw mask, not NaN-gated)
+        prev_avail = first.valid != 0;                                   // :848  (raw mask, not NaN-gated)
         ostart = 0;                                                      // :861-862 (in_outage = !prev_avail, start 0)
         status = prev_avail ? 0 : ST_HAD_OUTAGE;
         po_prev = first.p; ok_prev = quat_unit(first.q, r_prev); t_prev = first.t;
@@ -116,7 +116,7 @@ struct EkfTraj {
         dq.x = both_ok ? dq.x : 0.0; dq.y = both_ok ? dq.y : 0.0; dq.z = both_ok ? dq.z : 0.0; dq.w = both_ok ? dq.w : 1.0;
         status |= both_ok ? 0 : ST_BAD_QUAT;
         // ---- measurement gate, ref :867-869
-        const bool avail = in.valid && !(isnan(in.z.x) || isnan(in.z.y) || isnan(in.z.z));
+        const bool avail = (in.valid != 0) && !(isnan(in.z.x) || isnan(in.z.y) || isnan(in.z.z));
         const bool was_outage = !prev_avail;                             // in_gnss_outage before this step
         // ---- _predict, ref :702-715.  The reference re-normalises the state quaternion and the increment through
         // Rotation.from_quat; both are unit already (q leaves every step through ekf_normalize, dq is a product of two

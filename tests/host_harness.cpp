@@ -27,7 +27,7 @@ StepIn load_step(const double* ts, const double* pos, const double* quat, const 
     s.p = Vec3{ pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2] };
     s.q = Quat{ quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3] };
     s.z = Vec3{ gps[i * 3], gps[i * 3 + 1], gps[i * 3 + 2] };
-    s.valid = valid[i] != 0;
+    s.valid = valid[i];
     return s;
 }
 }  // namespace
