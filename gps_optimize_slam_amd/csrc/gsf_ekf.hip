@@ -226,8 +226,11 @@ extern "C" int gsf_ekf_fuse_batch_dev(gsf_ctx* ctx, int32_t layout, const double
             case 4: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 3, 1); break;
             default: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 2, 2); break;
         }
+    } else if (ctx->ekf_variant == 9) {
+        GSF_LAUNCH_EKF(GSF_LAYOUT_TRAJ_MAJOR, 2, 2);                   // lane-per-trajectory on strided rows (comparison only)
     } else {
-        GSF_LAUNCH_EKF(GSF_LAYOUT_TRAJ_MAJOR, 2, 2);
+        return launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr,
+                               pos_out, quat_out, status);             // wave-per-trajectory scans (gsf_ekf_wave.hip)
     }
 #undef GSF_LAUNCH_EKF
     GSF_HIP(hipGetLastError());
@@ -250,9 +253,11 @@ extern "C" int gsf_fuse_pipeline_batch_dev(gsf_ctx* ctx, int32_t layout, const d
     if (layout == GSF_LAYOUT_TIME_MAJOR)
         hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
                            R, t, s, pos_out, quat_out, status);
-    else
+    else if (ctx->ekf_variant == 9)
         hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TRAJ_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
                            R, t, s, pos_out, quat_out, status);
+    else
+        return launch_ekf_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

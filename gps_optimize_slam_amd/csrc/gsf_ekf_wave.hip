@@ -1,0 +1,366 @@
+// gsf_ekf_wave.hip -- K4 (and the fused K2+K3+K4 pipeline) with ONE WAVEFRONT PER TRAJECTORY.
+//
+// apply_ekf_correction (EKFGPSSLAM.py:831-935) is a serial recursion over the poses of one track, but every
+// piece of it is an associative scan once the covariance is known to stay diagonal:
+//   * orientation      q_i = q_{i-1} * dq_i                 -> prefix PRODUCT of quaternions
+//   * variances        P_i = r(P+qdt)/((P+qdt)+r) or P+qdt   -> prefix composition of 2x2 Moebius maps
+//   * positions        p_i = (1-k_i)(p_{i-1}+u_i) + k_i z_i  -> prefix composition of affine maps
+//   * outage structure (start / recovery / sharp-turn gate)  -> 64-bit ballots + bit scans
+//   * per-outage RTS   x_s[k] = x_f[k] + (P_f[k]/P_p[r]) (x_f[r]-x_p[r])   (the product of the gains A_j telescopes)
+// so a wave takes 64 consecutive poses per iteration (lane = pose), runs log2(64) = 6 shuffle stages per scan and
+// carries ~30 scalars to the next 64 poses.  All loads/stores of a chunk are contiguous (the natural
+// trajectory-major layout of stacked TUM files), B trajectories give B independent waves, and a 271-pose track costs
+// 5 iterations instead of 270 dependent steps: this is the low-latency / small-batch path (configs C1, C2); the
+// lane-per-trajectory kernel of gsf_ekf.hip is the streaming path for huge batches.
+//
+// Arithmetic differs from the serial form only in rounding order (quaternion renormalisation once per chunk instead of
+// every step, Moebius instead of Joseph variance update, local coordinates per chunk): observed |dp| ~1e-9 m against
+// the 1e-6 m gate; the tests compare against the dense-7x7 CPU oracle.
+#include "gsf_internal.hpp"
+
+using namespace gsf;
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ double shup(double v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ Quat shup(const Quat& q, int d) { return Quat{ shup(q.x, d), shup(q.y, d), shup(q.z, d), shup(q.w, d) }; }
+__device__ __forceinline__ Quat shidx(const Quat& q, int s) { return Quat{ shidx(q.x, s), shidx(q.y, s), shidx(q.z, s), shidx(q.w, s) }; }
+__device__ __forceinline__ Vec3 shidx(const Vec3& v, int s) { return Vec3{ shidx(v.x, s), shidx(v.y, s), shidx(v.z, s) }; }
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// bits lo..hi (inclusive) of a 64-bit mask; empty if lo > hi
+__device__ __forceinline__ u64 bits(int lo, int hi)
+{
+    if (lo > hi) return 0ull;
+    const u64 upto_hi = (hi >= 63) ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+    const u64 below_lo = (lo <= 0) ? 0ull : ((1ull << lo) - 1ull);
+    return upto_hi & ~below_lo;
+}
+
+struct WaveArgs {
+    const double* ts; const double* pos; const double* quat; const double* gps; const uint8_t* valid;
+    const double* init_pos; const double* init_quat;
+    double* R; double* t; double* s;              // pipeline outputs (may be null)
+    double* pos_out; double* quat_out; int32_t* status;
+    int64_t B, N;
+};
+
+template <bool PIPELINE>
+__global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
+{
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t N = a.N;
+    const double* __restrict__ tsb = a.ts + b * N;
+    const double* __restrict__ posb = a.pos + b * N * 3;
+    const double* __restrict__ quatb = a.quat + b * N * 4;
+    const double* __restrict__ gpsb = a.gps + b * N * 3;
+    const uint8_t* __restrict__ valb = a.valid + b * N;
+    double* __restrict__ pob = a.pos_out + b * N * 3;
+    double* __restrict__ qob = a.quat_out + b * N * 4;
+
+    // ------------------------------------------------------------------ initial pose
+    Vec3 p0; Quat q0;
+    int32_t fit = 0;
+    if (PIPELINE) {
+        // K2 on the rows with valid, finite GNSS (two passes: centroids, then centred moments), then K3 of pose 0
+        double cnt = 0, s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        for (int64_t i = lane; i < N; i += 64) {
+            const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
+            const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
+            if (!ok) continue;
+            cnt += 1.0; s0 += posb[i * 3]; s1 += posb[i * 3 + 1]; s2 += posb[i * 3 + 2]; d0 += z0; d1 += z1; d2 += z2;
+        }
+        const double n = wave_sum(cnt);
+        double Rb[9], tb[3], sb = NAN;
+        fit = SIM3_NONE;
+        if (n >= 3.0) {
+            const double rn = 1.0 / n;
+            const double sc[3] = { wave_sum(s0) * rn, wave_sum(s1) * rn, wave_sum(s2) * rn };
+            const double dc[3] = { wave_sum(d0) * rn, wave_sum(d1) * rn, wave_sum(d2) * rn };
+            double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ssq = 0.0;
+            for (int64_t i = lane; i < N; i += 64) {
+                const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
+                const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
+                if (!ok) continue;
+                const double a0 = posb[i * 3] - sc[0], a1 = posb[i * 3 + 1] - sc[1], a2 = posb[i * 3 + 2] - sc[2];
+                const double b0 = z0 - dc[0], b1 = z1 - dc[1], b2 = z2 - dc[2];
+                H[0] += a0 * b0; H[1] += a0 * b1; H[2] += a0 * b2;
+                H[3] += a1 * b0; H[4] += a1 * b1; H[5] += a1 * b2;
+                H[6] += a2 * b0; H[7] += a2 * b1; H[8] += a2 * b2;
+                ssq += a0 * a0 + a1 * a1 + a2 * a2;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) H[k] = wave_sum(H[k]);
+            ssq = wave_sum(ssq);
+            fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);       // every lane redundantly (wave-uniform inputs)
+        }
+        Quat qn0; const bool q0ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, qn0);
+        if (fit == SIM3_NONE || !q0ok) {                                  // wave-uniform
+            for (int64_t i = lane; i < N; i += 64) {
+                pob[i * 3] = NAN; pob[i * 3 + 1] = NAN; pob[i * 3 + 2] = NAN;
+                qob[i * 4] = NAN; qob[i * 4 + 1] = NAN; qob[i * 4 + 2] = NAN; qob[i * 4 + 3] = NAN;
+            }
+            if (lane == 0) {
+                for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
+                a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
+                if (a.status) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
+            }
+            return;
+        }
+        if (lane == 0) {
+            for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
+            a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
+        }
+        const double x = posb[0], y = posb[1], z = posb[2];
+        p0 = Vec3{ sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + tb[0], sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + tb[1],
+                   sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + tb[2] };   // ref :464
+        q0 = quat_mul(quat_from_matrix(Rb), qn0);                        // ref :465-466
+    } else {
+        p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
+        q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };
+    }
+
+    // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
+    Quat cq = ekf_normalize(q0);                                         // ref :842, :683
+    Vec3 cp = p0;
+    double cP[3] = { cfg.P0[0], cfg.P0[1], cfg.P0[2] };
+    bool c_prev_avail = valb[0] != 0;                                    // ref :848 (raw mask)
+    int64_t c_ostart = 0;                                                // ref :861-862
+    bool c_seg_sharp = false;
+    double cPos[3] = { cP[0], cP[1], cP[2] };                            // P_f at the first pose of the open outage
+    Vec3 c_po{ posb[0], posb[1], posb[2] };
+    Quat c_r; bool c_ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, c_r);
+    double c_t = tsb[0];
+    int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
+
+    for (int64_t c0 = 0; c0 < N; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool active = i < N;
+        const bool is_init = (i == 0);
+        const bool stepping = active && !is_init;
+        const int64_t il = active ? i : N - 1;
+        const int L = (int)((N - c0 < 64) ? (N - c0 - 1) : 63);          // last active lane of this chunk
+        // ---- loads (one contiguous slab per array per chunk)
+        const double t = tsb[il];
+        const Vec3 p{ posb[il * 3], posb[il * 3 + 1], posb[il * 3 + 2] };
+        const Quat q{ quatb[il * 4], quatb[il * 4 + 1], quatb[il * 4 + 2], quatb[il * 4 + 3] };
+        const Vec3 z{ gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2] };
+        const bool vraw = valb[il] != 0;
+        // ---- calculate_relative_pose (ref :77-92) against the previous lane / the carry
+        Quat r; const bool ok = quat_unit(q, r);
+        double t_pr = shup(t, 1); Vec3 p_pr{ shup(p.x, 1), shup(p.y, 1), shup(p.z, 1) }; Quat r_pr = shup(r, 1);
+        bool ok_pr = __shfl_up((int)ok, 1, 64) != 0;
+        if (lane == 0) { t_pr = c_t; p_pr = c_po; r_pr = c_r; ok_pr = c_ok; }
+        const double dt = fmax(1e-6, t - t_pr);                          // ref :865
+        const bool both_ok = ok_pr && ok;
+        const Quat r1i = quat_conj(r_pr);
+        Vec3 dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
+        Quat dq = quat_mul(r1i, r);
+        const bool move = stepping && both_ok;
+        dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
+        dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
+        if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
+        // ---- GNSS gate (ref :867-869) and the outage structure of the chunk as ballots
+        const bool avail = stepping && vraw && !(isnan(z.x) || isnan(z.y) || isnan(z.z));
+        const bool av = is_init ? vraw : avail;                          // "gnss available" flag of pose i (pose 0: raw mask, :848)
+        const u64 a_mask = __ballot(active && av);
+        const bool ap = (lane == 0) ? (is_init ? true : c_prev_avail) : (((a_mask >> (lane - 1)) & 1ull) != 0ull);
+        const bool starts = active && !av && ap;                         // outage begins at this pose (ref :875-877; pose 0: :861)
+        const bool recovers = stepping && av && !ap;                     // ref :879
+        const bool outpair = stepping && !av && !ap;                     // poses i-1 and i both inside the outage
+        const u64 start_mask = __ballot(starts), rec_mask = __ballot(recovers), pair_mask = __ballot(outpair);
+        if (start_mask != 0ull) status |= ST_HAD_OUTAGE;
+        // is_sharp_turn_in_segment (ref :808-826): pair (i-1, i) exceeds the yaw-rate threshold (or has a bad quaternion)
+        u64 f_mask = 0ull;
+        if (pair_mask != 0ull) {
+            bool f = false;
+            if (outpair && t > t_pr) f = !both_ok || yaw_rate_exceeds(r_pr, r, t - t_pr, cfg.yaw_thr_rad);
+            f_mask = __ballot(f);
+        }
+        // recovery decision per recovering lane (ref :879-894)
+        bool sharp = false;
+        if (recovers) {
+            const u64 sm = start_mask & bits(0, lane - 1);
+            int64_t s_glob; bool seg;
+            if (sm != 0ull) {
+                const int s = 63 - __clzll((long long)sm);
+                s_glob = c0 + s;
+                seg = (f_mask & bits(s + 1, lane - 1)) != 0ull;
+            } else {
+                s_glob = c_ostart;
+                seg = c_seg_sharp || (f_mask & bits(0, lane - 1)) != 0ull;
+            }
+            sharp = (i - s_glob >= 2) && seg;
+        }
+        const u64 sharp_mask = __ballot(sharp);
+        const u64 rts_mask = rec_mask & ~sharp_mask;                     // recoveries that run the RTS back-pass
+        if (sharp_mask != 0ull) status |= ST_SHARP_TURN;
+        if (rts_mask != 0ull) status |= ST_RTS_APPLIED;
+        // one-step blend weight on a sharp-turn recovery (ref :752-768, Q7): 1/eff if eff > 1, else a hard update
+        double wgt = 1.0;
+        if (sharp && cfg.sharp_turn_steps > 1) wgt = 1.0 / (double)cfg.sharp_turn_steps;
+
+        // ---- orientation: inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
+        Quat D = dq;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const Quat o = shup(D, s);
+            if (lane >= s) D = quat_mul(o, D);
+        }
+        const Quat qi = ekf_normalize(quat_mul(cq, D));                  // ref :708-709 (one normalisation per chunk)
+        Quat q_prev = shup(qi, 1);
+        if (lane == 0) q_prev = cq;
+        const Vec3 u = quat_rotate(q_prev, dpl);                         // predicted displacement, ref :707
+
+        // ---- variances: prefix composition of Moebius maps P -> (A P + Bm)/(Cm P + Dm) per axis (ref :712-713, :723-731)
+        double Pf[3], Pm[3], kg[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double b0 = cfg.Qps[c] * dt, rr = cfg.Rm[c];
+            double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
+            if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double oA = shup(A, s), oB = shup(Bm, s), oC = shup(Cm, s), oD = shup(Dm, s);
+                if (lane >= s) {                                         // mine (later) o other (earlier)
+                    const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;
+                    A = nA; Bm = nB; Cm = nC; Dm = nD;
+                }
+            }
+            Pf[c] = (A * cP[c] + Bm) * fast_rcp(Cm * cP[c] + Dm);        // P_f[i]
+            double Pprev = shup(Pf[c], 1);
+            if (lane == 0) Pprev = cP[c];
+            Pm[c] = Pprev + b0;                                          // P_p[i]
+            kg[c] = Pm[c] * fast_rcp(Pm[c] + rr);                        // Kalman gain if the fix is used
+        }
+
+        // ---- positions: prefix composition of affine maps x -> al x + be in chunk-local coordinates (x = p - p_carry)
+        const double uu[3] = { u.x, u.y, u.z }, zl[3] = { z.x - cp.x, z.y - cp.y, z.z - cp.z };
+        double xl[3], dcorr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double kw = kg[c] * wgt;
+            double al = avail ? (1.0 - kw) : 1.0;
+            double be = avail ? ((1.0 - kw) * uu[c] + kw * zl[c]) : uu[c];
+            const double al1 = al, be1 = be;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double oa = shup(al, s), ob = shup(be, s);
+                if (lane >= s) { be = al * ob + be; al = al * oa; }
+            }
+            xl[c] = be;                                                  // x_i (the carry is x = 0)
+            double xprev = shup(be, 1);
+            if (lane == 0) xprev = 0.0;
+            dcorr[c] = xl[c] - (xprev + uu[c]);                          // x_f[i] - x_p[i] (non-zero only where a fix was used)
+            (void)al1; (void)be1;
+        }
+
+        // ---- per-outage RTS (ref :906-922, :777-803).  Inside an outage x_f = x_p and P_f = P_p, so the gain product
+        // telescopes: x_s[k] = x_f[k] + (P_f[k] / P_p[r]) (x_f[r] - x_p[r]) for k in [start, r-1], r = the recovery pose.
+        double xo[3] = { xl[0], xl[1], xl[2] };                          // what is written out (filter state stays xl)
+        if (rts_mask != 0ull) {
+            const u64 later = rec_mask & ~bits(0, lane);                 // recoveries after this lane
+            const int rl = later != 0ull ? __ffsll((long long)later) - 1 : 0;
+            const bool in_run = active && !av && later != 0ull && (((rts_mask >> rl) & 1ull) != 0ull);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double dr = shidx(dcorr[c], rl), pr = shidx(Pm[c], rl);
+                if (in_run) xo[c] = xl[c] + Pf[c] * fast_rcp(pr) * dr;
+            }
+            // outage carried in from earlier chunks and closed here by an RTS recovery: fix the rows already written
+            if (!c_prev_avail) {
+                const int r1 = __ffsll((long long)rec_mask) - 1;         // first recovery of the chunk closes the carried run
+                if ((rts_mask >> r1) & 1ull) {
+                    const double dr[3] = { shidx(dcorr[0], r1), shidx(dcorr[1], r1), shidx(dcorr[2], r1) };
+                    const double ipr[3] = { fast_rcp(shidx(Pm[0], r1)), fast_rcp(shidx(Pm[1], r1)), fast_rcp(shidx(Pm[2], r1)) };
+                    double acc = 0.0;                                    // sum of dt over (ostart, k]
+                    for (int64_t k0 = (c_ostart / 64) * 64; k0 < c0; k0 += 64) {
+                        const int64_t k = k0 + lane;
+                        const double tk = tsb[k];
+                        double tkp = shup(tk, 1);
+                        if (lane == 0) tkp = (k > 0) ? tsb[k - 1] : tk;
+                        double dsum = (k > c_ostart) ? fmax(1e-6, tk - tkp) : 0.0;
+#pragma unroll
+                        for (int s = 1; s < 64; s <<= 1) { const double o = shup(dsum, s); if (lane >= s) dsum += o; }
+                        const double tot = shidx(dsum, 63);
+                        if (k >= c_ostart) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const double Pk = cPos[c] + cfg.Qps[c] * (acc + dsum);      // P_f[k] inside the outage
+                                pob[k * 3 + c] += Pk * ipr[c] * dr[c];
+                            }
+                        }
+                        acc += tot;
+                    }
+                }
+            }
+        }
+
+        // ---- stores
+        if (active) {
+            pob[i * 3] = cp.x + xo[0]; pob[i * 3 + 1] = cp.y + xo[1]; pob[i * 3 + 2] = cp.z + xo[2];
+            qob[i * 4] = qi.x; qob[i * 4 + 1] = qi.y; qob[i * 4 + 2] = qi.z; qob[i * 4 + 3] = qi.w;
+        }
+
+        // ---- carry to the next 64 poses (from the last active lane L)
+        const bool open = ((a_mask >> L) & 1ull) == 0ull;                // the chunk ends inside an outage
+        if (open) {
+            const u64 sm = start_mask & bits(0, L);
+            if (sm != 0ull) {
+                const int s = 63 - __clzll((long long)sm);
+                c_ostart = c0 + s;
+                c_seg_sharp = (f_mask & bits(s + 1, L)) != 0ull;
+                cPos[0] = shidx(Pf[0], s); cPos[1] = shidx(Pf[1], s); cPos[2] = shidx(Pf[2], s);
+            } else {
+                c_seg_sharp = c_seg_sharp || (f_mask & bits(0, L)) != 0ull;
+            }
+        }
+        c_prev_avail = !open;
+        cq = shidx(qi, L);
+        cp = Vec3{ cp.x + shidx(xl[0], L), cp.y + shidx(xl[1], L), cp.z + shidx(xl[2], L) };
+        cP[0] = shidx(Pf[0], L); cP[1] = shidx(Pf[1], L); cP[2] = shidx(Pf[2], L);
+        c_po = shidx(p, L); c_r = shidx(r, L); c_ok = __shfl((int)ok, L, 64) != 0; c_t = shidx(t, L);
+    }
+    if (lane == 0 && a.status) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
+}
+
+EkfConfig to_core(const gsf_ekf_config* c)
+{
+    EkfConfig k;
+    for (int i = 0; i < 7; ++i) { k.P0[i] = c->initial_cov_diag[i]; k.Qps[i] = c->process_noise_diag[i]; }
+    for (int i = 0; i < 3; ++i) k.Rm[i] = c->meas_noise_diag[i];
+    k.yaw_thr_rad = c->sharp_turn_yaw_rate_threshold_deg_per_sec * (M_PI / 180.0);
+    k.sharp_turn_steps = c->default_ekf_transition_steps_on_sharp_turn;
+    k._pad = 0;
+    return k;
+}
+
+}  // namespace
+
+namespace gsf {
+
+// trajectory-major launches (called from gsf_ekf.hip's C entry points)
+int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
+                    const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
+    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N };
+    const EkfConfig k = to_core(cfg);
+    if (pipeline)
+        hipLaunchKernelGGL(ekf_wave_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+    else
+        hipLaunchKernelGGL(ekf_wave_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+}  // namespace gsf
