@@ -5,7 +5,9 @@
 
 A "step" is one pass of the hot path over one batch of synthetic, HBM-resident trajectories: one launch of the fused
 pipeline kernel (Umeyama fit on the valid rows -> Sim3 of pose 0 -> EKF predict/update + per-outage RTS), i.e. steps
-3-5 of the reference's main_process_gui (EKFGPSSLAM.py:1002-1010) for every trajectory of the batch.
+3-5 of the reference's main_process_gui (EKFGPSSLAM.py:1002-1010) for every trajectory of the batch.  Two mappings exist
+(DESIGN.md): wave-per-trajectory scans on the trajectory-major layout (default for c2: few, short tracks) and
+lane-per-trajectory recursion on the time-major layout (default for c3: huge batches); --layout overrides.
 Workloads (BASELINE.json configs):
   c2 (default, configs[1]) 1k synthetic KITTI-04-length (271-pose) trajectories per GPU
   c3 (configs[2])          100k synthetic 1k-pose trajectories per GPU (HBM-bound regime)
@@ -46,7 +48,7 @@ def cpu_baseline(B_mod, torch, N, target_seconds=10.0):
         return time.perf_counter() - t0, nb * N
     dt, poses = run(probe_B, 99)
     rate = poses / dt
-    nb = int(max(probe_B, min(target_seconds * rate / N, 4e8 / (N * 160))))    # ~target_seconds of work, <= ~400 MB host
+    nb = int(max(probe_B, min(target_seconds * rate / N, 3e9 / (N * 160))))    # ~target_seconds of work, <= ~3 GB host
     dt, poses = run(nb, 100)
     return {"value": poses / dt, "unit": "fused poses/s", "cores": 1, "kind": "port",
             "sample": f"{nb} synthetic {N}-pose trajectories ({poses} poses, {dt:.1f} s) through oracle/gsf_oracle.c "
@@ -61,6 +63,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--ekf-variant", type=int, default=None, help="K4 tuning variant (gsf_set_option ekf_variant)")
     ap.add_argument("--kernel", choices=["pipeline", "ekf"], default="pipeline", help="step = fused pipeline (default) or K4 only")
+    ap.add_argument("--layout", choices=["traj", "time"], default=None, help="traj = trajectory-major (wave-per-trajectory kernel), time = time-major (lane-per-trajectory kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra C3 / per-kernel measurements")
     args = ap.parse_args()
@@ -83,6 +86,8 @@ def main():
     Bn, N = wl["B"], wl["N"]
     steps = args.steps if args.steps is not None else (200 if args.workload == "c2" else 10)
     warmup = args.warmup if args.warmup is not None else (20 if args.workload == "c2" else 2)
+    layout_name = args.layout or ("traj" if args.workload == "c2" else "time")
+    LAYOUT = B.LAYOUT_TRAJ_MAJOR if layout_name == "traj" else B.LAYOUT_TIME_MAJOR
     ctx = B.context()
     if args.ekf_variant is not None:
         ctx.set_option("ekf_variant", args.ekf_variant)
@@ -105,7 +110,7 @@ def main():
         return launch, out
 
     # ---- the timed workload: this rank's shard of world*B trajectories (ids [rank*B, (rank+1)*B))
-    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=B.LAYOUT_TIME_MAJOR, seed=20250523, traj0=rank * Bn)
+    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=LAYOUT, seed=20250523, traj0=rank * Bn)
     launch, out = make_step(batch)
     gather_bufs = None
     if world > 1:
@@ -137,11 +142,14 @@ def main():
     value = poses_per_step * steps / elapsed
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    kernel_name = "fuse_pipeline_kernel<TIME_MAJOR>" if args.kernel == "pipeline" else "ekf_fuse_kernel<TIME_MAJOR>"
+    if layout_name == "traj":
+        kernel_name = "ekf_wave_kernel<PIPELINE>" if args.kernel == "pipeline" else "ekf_wave_kernel<EKF>"
+    else:
+        kernel_name = "fuse_pipeline_kernel<TIME_MAJOR>" if args.kernel == "pipeline" else "ekf_fuse_kernel<TIME_MAJOR>"
     result = {
         "metric": "fused poses/sec (whole node)", "value": value, "unit": "fused poses/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "time-major SoA", "step": args.kernel,
+        "config": {"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)" if layout_name == "traj" else "time-major SoA (lane-per-trajectory)", "step": args.kernel,
                    "parallelism": f"trajectory-sharded x{world}" + (", RCCL all-gather of fused poses per step" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
@@ -151,7 +159,7 @@ def main():
         import numpy as np
         from oracle import oracle as orc
         nb = min(Bn, 64)
-        sub = B.TrajectoryBatch.synthetic(nb, N, layout=B.LAYOUT_TIME_MAJOR, seed=20250523, traj0=0)
+        sub = B.TrajectoryBatch.synthetic(nb, N, layout=LAYOUT, seed=20250523, traj0=0)
         so = B.ekf_fuse_batch(sub)
         h = sub.host_traj_major()
         p, q, st = so.host_traj_major()
@@ -172,17 +180,20 @@ def main():
                 fn()
             b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
-        for name, (b3, n3, reps) in {"c3_100k_x_1k": (100_000, 1000, 5), "c2_1k_x_271": (1000, 271, 50)}.items():
-            bt = B.TrajectoryBatch.synthetic(b3, n3, layout=B.LAYOUT_TIME_MAJOR, seed=1)
-            o = B.FusedPoses(bt.layout, b3, n3, dev)
-            ms_e = timed(lambda: B.ekf_fuse_batch(bt, out=o), reps)
-            ms_p = timed(lambda: B.fuse_pipeline_batch(bt, out=o), reps)
+        for name, (b3, n3, reps) in {"c3_100k_x_1k": (100_000, 1000, 5), "c2_1k_x_271": (1000, 271, 100)}.items():
             ab = b3 * n3 * ALG_BYTES_PER_POSE
-            extra[name] = {"ekf_kernel_ms": ms_e, "ekf_poses_per_s": b3 * n3 / ms_e * 1e3, "ekf_alg_GBps": ab / ms_e / 1e6, "ekf_hbm_frac": ab / ms_e / 1e6 / HBM_PEAK_GBS,
-                           "pipeline_kernel_ms": ms_p, "pipeline_poses_per_s": b3 * n3 / ms_p * 1e3, "pipeline_alg_GBps": ab / ms_p / 1e6,
-                           "pipeline_hbm_frac": ab / ms_p / 1e6 / HBM_PEAK_GBS}
-            del bt, o
-            torch.cuda.empty_cache()
+            extra[name] = {}
+            for lname, lay in (("time_major_lane_per_traj", B.LAYOUT_TIME_MAJOR), ("traj_major_wave_per_traj", B.LAYOUT_TRAJ_MAJOR)):
+                bt = B.TrajectoryBatch.synthetic(b3, n3, layout=lay, seed=1)
+                o = B.FusedPoses(bt.layout, b3, n3, dev)
+                ms_e = timed(lambda: B.ekf_fuse_batch(bt, out=o), reps)
+                ms_p = timed(lambda: B.fuse_pipeline_batch(bt, out=o), reps)
+                extra[name][lname] = {"ekf_kernel_ms": ms_e, "ekf_poses_per_s": b3 * n3 / ms_e * 1e3, "ekf_alg_GBps": ab / ms_e / 1e6,
+                                      "ekf_hbm_frac": ab / ms_e / 1e6 / HBM_PEAK_GBS, "pipeline_kernel_ms": ms_p,
+                                      "pipeline_poses_per_s": b3 * n3 / ms_p * 1e3, "pipeline_alg_GBps": ab / ms_p / 1e6,
+                                      "pipeline_hbm_frac": ab / ms_p / 1e6 / HBM_PEAK_GBS}
+                del bt, o
+                torch.cuda.empty_cache()
         result["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, torch, N)
