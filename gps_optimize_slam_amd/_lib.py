@@ -80,6 +80,11 @@ SIGNATURES = {
     "gsf_ekf_fuse_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_ekf_fuse_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_relative_pose_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gsf_quaternion_nlerp_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "gsf_is_sharp_turn_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp]),
+    "gsf_ekf_process_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_f64), _i32, _vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp]),
+    "gsf_rts_smoother_segment_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gsf_transpose_to_time_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsf_transpose_to_traj_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsf_synth_batch_dev": (C.c_int, [_vp, _i32, C.c_uint64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

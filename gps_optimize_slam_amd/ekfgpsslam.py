@@ -363,6 +363,101 @@ def ekf_fuse_aligned(timestamps, positions, quaternions, aligned_gps, valid_mask
     return po, qo, int(st[0])
 
 
+# ---------------------------------------------------------------------------- helpers of the EKF surface (EKFGPSSLAM.py:77-105, :679-826)
+def calculate_relative_pose(pose1_pos, pose1_quat, pose2_pos, pose2_quat):
+    """Relative motion pose1 -> pose2 in pose1's frame: (delta_pos_local (3,), delta_quat (4,)); an invalid (zero-norm)
+    quaternion gives zero motion and the identity (ref :77-92)."""
+    p1, q1, p2, q2 = f64(pose1_pos, (1, 3)), f64(pose1_quat, (1, 4)), f64(pose2_pos, (1, 3)), f64(pose2_quat, (1, 4))
+    dp, dq = np.empty((1, 3)), np.empty((1, 4))
+    check(_lib.load().gsf_relative_pose_batch(_ctx().handle, hptr(p1), hptr(q1), hptr(p2), hptr(q2), 1, hptr(dp), hptr(dq), None))
+    return dp[0], dq[0]
+
+
+def quaternion_nlerp(q1, q2, weight_q2):
+    """Normalised linear interpolation between two quaternions (ref :94-105)."""
+    a, b, w, out = f64(q1, (1, 4)), f64(q2, (1, 4)), np.array([float(weight_q2)]), np.empty((1, 4))
+    check(_lib.load().gsf_quaternion_nlerp_batch(_ctx().handle, hptr(a), hptr(b), hptr(w), 1, hptr(out)))
+    return out[0]
+
+
+def is_sharp_turn_in_segment(slam_quaternions_segment, slam_timestamps_segment, yaw_rate_threshold_rad_per_sec):
+    """True if the max |yaw rate| over consecutive poses of the segment exceeds the threshold (ref :808-826)."""
+    n = len(slam_quaternions_segment)
+    if n < 2:
+        return False
+    q, t = f64(np.asarray(slam_quaternions_segment), (n, 4)), f64(np.asarray(slam_timestamps_segment), (n,))
+    off, res = np.array([0, n], dtype=np.int64), np.zeros(1, dtype=np.int32)
+    check(_lib.load().gsf_is_sharp_turn_batch(_ctx().handle, hptr(q), hptr(t), hptr(off), 1, float(yaw_rate_threshold_rad_per_sec), hptr(res), None))
+    return bool(res[0])
+
+
+def rts_smoother_segment(states_filt_segment, covs_filt_segment, states_pred_segment, covs_pred_segment):
+    """RTS back-pass over one segment, F = I (ref :777-803).  Lists in, lists of arrays out, like the reference."""
+    n = len(states_filt_segment)
+    if n == 0:
+        return [], []
+    xf, xp = f64(np.asarray(states_filt_segment), (n, 7)), f64(np.asarray(states_pred_segment), (n, 7))
+    Pf, Pp = f64(np.asarray(covs_filt_segment), (n, 49)), f64(np.asarray(covs_pred_segment), (n, 49))
+    xs, Ps, off = np.empty((n, 7)), np.empty((n, 49)), np.array([0, n], dtype=np.int64)
+    check(_lib.load().gsf_rts_smoother_segment_batch(_ctx().handle, hptr(xf), hptr(Pf), hptr(xp), hptr(Pp), hptr(off), 1, hptr(xs), hptr(Ps)))
+    return [xs[k].copy() for k in range(n)], [Ps[k].reshape(7, 7).copy() for k in range(n)]
+
+
+class ExtendedKalmanFilter:
+    """The reference's 7-state filter object (ref :679-772): same attributes and process_step signature; every step is one
+    device call in the general dense-covariance form (gsf_ekf_process_step).  The batched hot path does not go through this
+    class -- it exists so that code written against the reference's class keeps working."""
+
+    def __init__(self, initial_pos, initial_quat, config_params):
+        initial_pos, initial_quat = np.asarray(initial_pos, dtype=float), np.asarray(initial_quat, dtype=float)
+        if not (initial_pos.shape == (3,) and initial_quat.shape == (4,)):
+            raise ValueError("EKF init: initial pose must be pos (3,) and quat (4,)")
+        self.state = np.concatenate([initial_pos, self.normalize_quaternion(initial_quat)]).astype(float)
+        self.cov = np.diag(config_params["initial_cov_diag"]).astype(float)
+        self.Q_per_sec = np.diag(config_params["process_noise_diag"]).astype(float)
+        self.R = np.diag(config_params["meas_noise_diag"]).astype(float)
+        if self.state.shape != (7,) or self.cov.shape != (7, 7) or self.Q_per_sec.shape != (7, 7) or self.R.shape != (3, 3):
+            raise ValueError("EKF init: wrong state / covariance / noise dimensions")
+        self.gnss_available_prev = None
+        self.gnss_update_weight = 0.0
+        self.original_transition_steps = max(1, int(config_params.get("transition_steps", 10)))
+        self.current_transition_steps = self.original_transition_steps
+        self.weight_delta = 1.0
+        self._last_predicted_state_for_blending = self.state.copy()
+
+    @staticmethod
+    def normalize_quaternion(q):
+        q = np.asarray(q, dtype=float)
+        norm = np.linalg.norm(q)
+        return q / norm if norm > 1e-9 else np.array([0.0, 0.0, 0.0, 1.0])
+
+    def process_step(self, slam_motion_update, gps_measurement, gnss_is_available, delta_time, override_transition_steps=None):
+        eff = override_transition_steps if override_transition_steps is not None else self.current_transition_steps
+        self.weight_delta = 1.0 / eff if eff > 0 else 1.0
+        state, cov = f64(self.state, (7,)).copy(), f64(self.cov, (49,)).copy()
+        Q, R = f64(self.Q_per_sec, (49,)), f64(self.R, (9,))
+        dp, dq = f64(slam_motion_update[0], (3,)), f64(slam_motion_update[1], (4,))
+        z = None
+        if gps_measurement is not None:
+            z = np.asarray(gps_measurement, dtype=float)
+            if z.shape != (3,):
+                z = None                                  # ref :719: wrong shape -> the update is skipped
+            else:
+                z = np.ascontiguousarray(z)
+        prev = C.c_int32({None: -1, False: 0, True: 1}[None if self.gnss_available_prev is None else bool(self.gnss_available_prev)])
+        w = C.c_double(float(self.gnss_update_weight))
+        ps, pc = np.empty(7), np.empty(49)
+        check(_lib.load().gsf_ekf_process_step(_ctx().handle, hptr(state), hptr(cov), hptr(Q), hptr(R), C.byref(prev), C.byref(w),
+                                               int(self.current_transition_steps), hptr(dp), hptr(dq), hptr(z), int(bool(gnss_is_available)),
+                                               float(delta_time), -1 if override_transition_steps is None else int(override_transition_steps),
+                                               hptr(ps), hptr(pc)))
+        self.state, self.cov = state, cov.reshape(7, 7)
+        self.gnss_available_prev = bool(gnss_is_available)
+        self.gnss_update_weight = w.value
+        self._last_predicted_state_for_blending = ps.copy()
+        return self.state, self.cov, ps, pc.reshape(7, 7)
+
+
 # ---------------------------------------------------------------------------- headless driver (EKFGPSSLAM.py:940-1104, no GUI)
 def pick_sim3_indices(slam_data, valid_mask, config=None):
     """Which time-synchronised points feed the global Sim3 (first gap-free segment, <= max_initial_duration) -- ref :973-998."""

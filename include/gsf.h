@@ -167,6 +167,27 @@ GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const doub
                                 const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
                                 double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
 
+/* ---- helper functions of the reference's EKF surface (API completeness; host pointers, synchronous) ------------ */
+/* calculate_relative_pose (EKFGPSSLAM.py:77-92) for n pose pairs; bad[i]=1 where the zero-motion branch (:84-86) was taken */
+GSF_API int gsf_relative_pose_batch(gsf_ctx *ctx, const double *p1, const double *q1, const double *p2, const double *q2, int64_t n,
+                                    double *delta_pos_local, double *delta_quat, int32_t *bad);
+/* quaternion_nlerp (EKFGPSSLAM.py:94-105) for n pairs */
+GSF_API int gsf_quaternion_nlerp_batch(gsf_ctx *ctx, const double *q1, const double *q2, const double *weight_q2, int64_t n, double *out);
+/* is_sharp_turn_in_segment (EKFGPSSLAM.py:808-826) for B ragged segments: result[b] in {0,1}, max_rate[b] rad/s (may be NULL) */
+GSF_API int gsf_is_sharp_turn_batch(gsf_ctx *ctx, const double *quats, const double *stamps, const int64_t *offsets, int64_t B,
+                                    double yaw_rate_threshold_rad_per_sec, int32_t *result, double *max_rate);
+/* one ExtendedKalmanFilter.process_step (EKFGPSSLAM.py:736-772) in the reference's general dense form: state[7], cov[49],
+   Q_per_sec[49], R[9]; gnss_available_prev in {-1 None, 0, 1}; gps_meas NULL = None; override_transition_steps < 0 = None */
+GSF_API int gsf_ekf_process_step(gsf_ctx *ctx, double *state, double *cov, const double *process_noise_per_sec, const double *meas_noise,
+                                 int32_t *gnss_available_prev, double *gnss_update_weight, int32_t current_transition_steps,
+                                 const double *delta_pos_local, const double *delta_quat, const double *gps_meas,
+                                 int32_t gnss_is_available, double delta_time, int32_t override_transition_steps, double *pred_state,
+                                 double *pred_cov);
+/* rts_smoother_segment (EKFGPSSLAM.py:777-803), dense 7x7, for B ragged segments (rows offsets[b]..offsets[b+1]) */
+GSF_API int gsf_rts_smoother_segment_batch(gsf_ctx *ctx, const double *states_filt, const double *covs_filt, const double *states_pred,
+                                           const double *covs_pred, const int64_t *offsets, int64_t B, double *states_smooth,
+                                           double *covs_smooth);
+
 /* ---- layout helpers + synthetic workload (bench / tests) ------------------------------------------ */
 /* [B][N][C] <-> [N][C][B] transposes of float64 (C = 1,3,4) and uint8 (C = 1) arrays, on device */
 GSF_API int gsf_transpose_to_time_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);

@@ -328,3 +328,51 @@ def test_full_size_properties(B):
     assert torch.isfinite(out.pos).all() and torch.isfinite(out.quat).all()
     unit = out.quat.pow(2).sum(dim=1)
     assert (unit - 1).abs().max().item() < 1e-12
+
+
+# ------------------------------------------------------------------ helper functions of the EKF surface (a5, a9-a12)
+def test_relative_pose_and_nlerp(E, golden):
+    g = golden("helper_cases.npz")
+    for i in range(len(g["rp_p1"])):
+        dp, dq = E.calculate_relative_pose(g["rp_p1"][i], g["rp_q1"][i], g["rp_p2"][i], g["rp_q2"][i])
+        np.testing.assert_allclose(dp, g["rp_dp"][i], atol=1e-13, rtol=0)
+        np.testing.assert_allclose(dq, g["rp_dq"][i], atol=1e-15, rtol=0)
+    for a, b, w, o in zip(g["nl_a"], g["nl_b"], g["nl_w"], g["nl_out"]):
+        np.testing.assert_allclose(E.quaternion_nlerp(a, b, w), o, atol=1e-15, rtol=0)
+
+
+def test_sharp_turn_function(E, golden):
+    g = golden("helper_cases.npz")
+    for name in g["sh_names"]:
+        r = E.is_sharp_turn_in_segment(list(g[f"sh_{name}_q"]), list(g[f"sh_{name}_t"]), float(g[f"sh_{name}_thr"]))
+        assert r == bool(g[f"sh_{name}_r"]), name
+
+
+@pytest.mark.parametrize("tag", ["diag", "dense"])
+def test_rts_smoother_segment_function(E, golden, tag):
+    g = golden("helper_cases.npz")
+    xs, Ps = E.rts_smoother_segment(list(g[f"rts_{tag}_xf"]), list(g[f"rts_{tag}_Pf"]), list(g[f"rts_{tag}_xp"]), list(g[f"rts_{tag}_Pp"]))
+    tol = 1e-12 if tag == "diag" else 1e-9
+    np.testing.assert_allclose(np.array(xs), g[f"rts_{tag}_xs"], atol=tol, rtol=tol)
+    np.testing.assert_allclose(np.array(Ps), g[f"rts_{tag}_Ps"], atol=tol * 10, rtol=tol * 10)
+    assert E.rts_smoother_segment([], [], [], []) == ([], [])
+
+
+@pytest.mark.parametrize("tag", ["hard", "blend4", "override3"])
+def test_extended_kalman_filter_class(E, golden, tag):
+    g = golden("helper_cases.npz")
+    steps, ovr = (int(v) for v in g[f"ps_{tag}_par"])
+    f = E.ExtendedKalmanFilter(np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2, 0.3, 0.9]) * 2, E.CONFIG["ekf"])
+    f.current_transition_steps = steps
+    f.gnss_available_prev = False
+    for i in range(len(g[f"ps_{tag}_dt"])):
+        av = bool(g[f"ps_{tag}_avail"][i])
+        st, cv, ps, pc = f.process_step((g[f"ps_{tag}_dp"][i], g[f"ps_{tag}_dq"][i]), g[f"ps_{tag}_z"][i] if av else None, av,
+                                        float(g[f"ps_{tag}_dt"][i]), override_transition_steps=None if ovr < 0 else ovr)
+        np.testing.assert_allclose(st, g[f"ps_{tag}_state"][i], atol=1e-12, rtol=0)
+        np.testing.assert_allclose(cv, g[f"ps_{tag}_cov"][i], atol=1e-14, rtol=0)
+        np.testing.assert_allclose(ps, g[f"ps_{tag}_ps"][i], atol=1e-12, rtol=0)
+        np.testing.assert_allclose(pc, g[f"ps_{tag}_pc"][i], atol=1e-14, rtol=0)
+        assert abs(f.gnss_update_weight - float(g[f"ps_{tag}_w"][i])) < 1e-15
+    with pytest.raises(ValueError):
+        E.ExtendedKalmanFilter(np.zeros(2), np.zeros(4), E.CONFIG["ekf"])
