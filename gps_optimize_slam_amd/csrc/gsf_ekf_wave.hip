@@ -24,11 +24,41 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ double shup(double v, int d) { return __shfl_up(v, d, 64); }
-__device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ Quat shup(const Quat& q, int d) { return Quat{ shup(q.x, d), shup(q.y, d), shup(q.z, d), shup(q.w, d) }; }
-__device__ __forceinline__ Quat shidx(const Quat& q, int s) { return Quat{ shidx(q.x, s), shidx(q.y, s), shidx(q.z, s), shidx(q.w, s) }; }
-__device__ __forceinline__ Vec3 shidx(const Vec3& v, int s) { return Vec3{ shidx(v.x, s), shidx(v.y, s), shidx(v.z, s) }; }
+// ---- cross-lane movement.  The scans run on DPP (data-parallel-primitive) operand routing -- a VALU move, no LDS round
+// trip: row_shr:1/2/4/8 inside the four 16-lane rows, then row_bcast:15 (rows 1,3 <- lane 15 of the row before) and
+// row_bcast:31 (rows 2,3 <- lane 31).  Lanes without a source keep `old`, which is passed as the IDENTITY of the scanned
+// monoid, so every stage is an unconditional "other o mine".  ds_bpermute (__shfl) is kept only for per-lane indices.
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp(double old, double v)
+{
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Quat dpp(const Quat& old, const Quat& v)
+{
+    return Quat{ dpp<CTRL, ROW_MASK>(old.x, v.x), dpp<CTRL, ROW_MASK>(old.y, v.y), dpp<CTRL, ROW_MASK>(old.z, v.z), dpp<CTRL, ROW_MASK>(old.w, v.w) };
+}
+// value of the previous lane; lane 0 receives `carry`
+__device__ __forceinline__ double prev_lane(double carry, double v) { return dpp<DPP_WAVE_SHR1, 0xf>(carry, v); }
+__device__ __forceinline__ Quat prev_lane(const Quat& c, const Quat& v) { return dpp<DPP_WAVE_SHR1, 0xf>(c, v); }
+// wave-uniform source lane -> v_readlane (result lives in SGPRs)
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)x, src), hi = __builtin_amdgcn_readlane((int)(x >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ Quat lane_bcast(const Quat& q, int s) { return Quat{ lane_bcast(q.x, s), lane_bcast(q.y, s), lane_bcast(q.z, s), lane_bcast(q.w, s) }; }
+__device__ __forceinline__ Vec3 lane_bcast(const Vec3& v, int s) { return Vec3{ lane_bcast(v.x, s), lane_bcast(v.y, s), lane_bcast(v.z, s) }; }
+__device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, src, 64); }          // per-lane source index
+#define GSF_SCAN_STAGES(STAGE) STAGE(DPP_ROW_SHR1, 0xf) STAGE(DPP_ROW_SHR2, 0xf) STAGE(DPP_ROW_SHR4, 0xf) STAGE(DPP_ROW_SHR8, 0xf) \
+                               STAGE(DPP_ROW_BCAST15, 0xa) STAGE(DPP_ROW_BCAST31, 0xc)
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -156,9 +186,11 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
         const bool vraw = valb[il] != 0;
         // ---- calculate_relative_pose (ref :77-92) against the previous lane / the carry
         Quat r; const bool ok = quat_unit(q, r);
-        double t_pr = shup(t, 1); Vec3 p_pr{ shup(p.x, 1), shup(p.y, 1), shup(p.z, 1) }; Quat r_pr = shup(r, 1);
-        bool ok_pr = __shfl_up((int)ok, 1, 64) != 0;
-        if (lane == 0) { t_pr = c_t; p_pr = c_po; r_pr = c_r; ok_pr = c_ok; }
+        const double t_pr = prev_lane(c_t, t);
+        const Vec3 p_pr{ prev_lane(c_po.x, p.x), prev_lane(c_po.y, p.y), prev_lane(c_po.z, p.z) };
+        const Quat r_pr = prev_lane(c_r, r);
+        const u64 ok_mask = __ballot(ok);
+        const bool ok_pr = (lane == 0) ? c_ok : (((ok_mask >> (lane - 1)) & 1ull) != 0ull);
         const double dt = fmax(1e-6, t - t_pr);                          // ref :865
         const bool both_ok = ok_pr && ok;
         const Quat r1i = quat_conj(r_pr);
@@ -210,14 +242,12 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 
         // ---- orientation: inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
         Quat D = dq;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const Quat o = shup(D, s);
-            if (lane >= s) D = quat_mul(o, D);
-        }
+        const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
+#define GSF_QSTAGE(CTRL, RM) { const Quat o = dpp<CTRL, RM>(QID, D); D = quat_mul(o, D); }
+        GSF_SCAN_STAGES(GSF_QSTAGE)
+#undef GSF_QSTAGE
         const Quat qi = ekf_normalize(quat_mul(cq, D));                  // ref :708-709 (one normalisation per chunk)
-        Quat q_prev = shup(qi, 1);
-        if (lane == 0) q_prev = cq;
+        const Quat q_prev = prev_lane(cq, qi);
         const Vec3 u = quat_rotate(q_prev, dpl);                         // predicted displacement, ref :707
 
         // ---- variances: prefix composition of Moebius maps P -> (A P + Bm)/(Cm P + Dm) per axis (ref :712-713, :723-731)
@@ -227,18 +257,15 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
             const double b0 = cfg.Qps[c] * dt, rr = cfg.Rm[c];
             double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
             if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const double oA = shup(A, s), oB = shup(Bm, s), oC = shup(Cm, s), oD = shup(Dm, s);
-                if (lane >= s) {                                         // mine (later) o other (earlier)
-                    const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;
-                    A = nA; Bm = nB; Cm = nC; Dm = nD;
-                }
-            }
+            // mine (later) o other (earlier); lanes without a source see the identity map (1,0;0,1)
+#define GSF_MSTAGE(CTRL, RM) {                                                                                              \
+                const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp<CTRL, RM>(0.0, Bm), oC = dpp<CTRL, RM>(0.0, Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
+                const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
+                A = nA; Bm = nB; Cm = nC; Dm = nD; }
+            GSF_SCAN_STAGES(GSF_MSTAGE)
+#undef GSF_MSTAGE
             Pf[c] = (A * cP[c] + Bm) * fast_rcp(Cm * cP[c] + Dm);        // P_f[i]
-            double Pprev = shup(Pf[c], 1);
-            if (lane == 0) Pprev = cP[c];
-            Pm[c] = Pprev + b0;                                          // P_p[i]
+            Pm[c] = prev_lane(cP[c], Pf[c]) + b0;                        // P_p[i]
             kg[c] = Pm[c] * fast_rcp(Pm[c] + rr);                        // Kalman gain if the fix is used
         }
 
@@ -250,17 +277,11 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
             const double kw = kg[c] * wgt;
             double al = avail ? (1.0 - kw) : 1.0;
             double be = avail ? ((1.0 - kw) * uu[c] + kw * zl[c]) : uu[c];
-            const double al1 = al, be1 = be;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const double oa = shup(al, s), ob = shup(be, s);
-                if (lane >= s) { be = al * ob + be; al = al * oa; }
-            }
+#define GSF_ASTAGE(CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al), ob = dpp<CTRL, RM>(0.0, be); be = al * ob + be; al = al * oa; }
+            GSF_SCAN_STAGES(GSF_ASTAGE)
+#undef GSF_ASTAGE
             xl[c] = be;                                                  // x_i (the carry is x = 0)
-            double xprev = shup(be, 1);
-            if (lane == 0) xprev = 0.0;
-            dcorr[c] = xl[c] - (xprev + uu[c]);                          // x_f[i] - x_p[i] (non-zero only where a fix was used)
-            (void)al1; (void)be1;
+            dcorr[c] = xl[c] - (prev_lane(0.0, be) + uu[c]);             // x_f[i] - x_p[i] (non-zero only where a fix was used)
         }
 
         // ---- per-outage RTS (ref :906-922, :777-803).  Inside an outage x_f = x_p and P_f = P_p, so the gain product
@@ -279,18 +300,18 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
             if (!c_prev_avail) {
                 const int r1 = __ffsll((long long)rec_mask) - 1;         // first recovery of the chunk closes the carried run
                 if ((rts_mask >> r1) & 1ull) {
-                    const double dr[3] = { shidx(dcorr[0], r1), shidx(dcorr[1], r1), shidx(dcorr[2], r1) };
-                    const double ipr[3] = { fast_rcp(shidx(Pm[0], r1)), fast_rcp(shidx(Pm[1], r1)), fast_rcp(shidx(Pm[2], r1)) };
+                    const double dr[3] = { lane_bcast(dcorr[0], r1), lane_bcast(dcorr[1], r1), lane_bcast(dcorr[2], r1) };
+                    const double ipr[3] = { fast_rcp(lane_bcast(Pm[0], r1)), fast_rcp(lane_bcast(Pm[1], r1)), fast_rcp(lane_bcast(Pm[2], r1)) };
                     double acc = 0.0;                                    // sum of dt over (ostart, k]
                     for (int64_t k0 = (c_ostart / 64) * 64; k0 < c0; k0 += 64) {
                         const int64_t k = k0 + lane;
                         const double tk = tsb[k];
-                        double tkp = shup(tk, 1);
-                        if (lane == 0) tkp = (k > 0) ? tsb[k - 1] : tk;
+                        const double tkp = prev_lane((k0 > 0) ? tsb[k0 - 1] : tk, tk);
                         double dsum = (k > c_ostart) ? fmax(1e-6, tk - tkp) : 0.0;
-#pragma unroll
-                        for (int s = 1; s < 64; s <<= 1) { const double o = shup(dsum, s); if (lane >= s) dsum += o; }
-                        const double tot = shidx(dsum, 63);
+#define GSF_SSTAGE(CTRL, RM) { dsum += dpp<CTRL, RM>(0.0, dsum); }
+                        GSF_SCAN_STAGES(GSF_SSTAGE)
+#undef GSF_SSTAGE
+                        const double tot = lane_bcast(dsum, 63);
                         if (k >= c_ostart) {
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
@@ -318,16 +339,16 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
                 const int s = 63 - __clzll((long long)sm);
                 c_ostart = c0 + s;
                 c_seg_sharp = (f_mask & bits(s + 1, L)) != 0ull;
-                cPos[0] = shidx(Pf[0], s); cPos[1] = shidx(Pf[1], s); cPos[2] = shidx(Pf[2], s);
+                cPos[0] = lane_bcast(Pf[0], s); cPos[1] = lane_bcast(Pf[1], s); cPos[2] = lane_bcast(Pf[2], s);
             } else {
                 c_seg_sharp = c_seg_sharp || (f_mask & bits(0, L)) != 0ull;
             }
         }
         c_prev_avail = !open;
-        cq = shidx(qi, L);
-        cp = Vec3{ cp.x + shidx(xl[0], L), cp.y + shidx(xl[1], L), cp.z + shidx(xl[2], L) };
-        cP[0] = shidx(Pf[0], L); cP[1] = shidx(Pf[1], L); cP[2] = shidx(Pf[2], L);
-        c_po = shidx(p, L); c_r = shidx(r, L); c_ok = __shfl((int)ok, L, 64) != 0; c_t = shidx(t, L);
+        cq = lane_bcast(qi, L);
+        cp = Vec3{ cp.x + lane_bcast(xl[0], L), cp.y + lane_bcast(xl[1], L), cp.z + lane_bcast(xl[2], L) };
+        cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
+        c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
     }
     if (lane == 0 && a.status) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }
