@@ -59,11 +59,13 @@ __device__ __forceinline__ Vec3 lane_bcast(const Vec3& v, int s) { return Vec3{ 
 __device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, src, 64); }          // per-lane source index
 #define GSF_SCAN_STAGES(STAGE) STAGE(DPP_ROW_SHR1, 0xf) STAGE(DPP_ROW_SHR2, 0xf) STAGE(DPP_ROW_SHR4, 0xf) STAGE(DPP_ROW_SHR8, 0xf) \
                                STAGE(DPP_ROW_BCAST15, 0xa) STAGE(DPP_ROW_BCAST31, 0xc)
+// sum over the wave: inclusive DPP scan, total read from lane 63 (wave-uniform result)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define GSF_SUMSTAGE(CTRL, RM) { v += dpp<CTRL, RM>(0.0, v); }
+    GSF_SCAN_STAGES(GSF_SUMSTAGE)
+#undef GSF_SUMSTAGE
+    return lane_bcast(v, 63);
 }
 // bits lo..hi (inclusive) of a 64-bit mask; empty if lo > hi
 __device__ __forceinline__ u64 bits(int lo, int hi)
@@ -100,36 +102,47 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
     Vec3 p0; Quat q0;
     int32_t fit = 0;
     if (PIPELINE) {
-        // K2 on the rows with valid, finite GNSS (two passes: centroids, then centred moments), then K3 of pose 0
-        double cnt = 0, s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        // K2 on the rows with valid, finite GNSS, ONE pass: moments of the data shifted by pose 0 / the first finite fix
+        // (|shifted| <= track length, so the raw-moment form H = Sab - n ma mb^T loses nothing at UTM magnitudes), then K3
+        // of pose 0.  Sums are per-lane partials + a DPP wave reduction.
+        const double as0 = posb[0], as1 = posb[1], as2 = posb[2];
+        double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
+        {   // shift for the GNSS side: the first valid finite fix of the track (wave-uniform)
+            bool found = false;
+            for (int64_t c0 = 0; c0 < N && !found; c0 += 64) {
+                const int64_t i = c0 + lane;
+                bool ok = false; double z0 = 0, z1 = 0, z2 = 0;
+                if (i < N) { z0 = gpsb[i * 3]; z1 = gpsb[i * 3 + 1]; z2 = gpsb[i * 3 + 2]; ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2)); }
+                const u64 m = __ballot(ok);
+                if (m != 0ull) { const int f = __ffsll((long long)m) - 1; bs0 = lane_bcast(z0, f); bs1 = lane_bcast(z1, f); bs2 = lane_bcast(z2, f); found = true; }
+            }
+        }
+        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+        double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int64_t i = lane; i < N; i += 64) {
             const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
             const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
             if (!ok) continue;
-            cnt += 1.0; s0 += posb[i * 3]; s1 += posb[i * 3 + 1]; s2 += posb[i * 3 + 2]; d0 += z0; d1 += z1; d2 += z2;
+            const double a0 = posb[i * 3] - as0, a1 = posb[i * 3 + 1] - as1, a2 = posb[i * 3 + 2] - as2;
+            const double b0 = z0 - bs0, b1 = z1 - bs1, b2 = z2 - bs2;
+            cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
+            Saa += a0 * a0 + a1 * a1 + a2 * a2;
+            Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
+            Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
+            Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
         }
         const double n = wave_sum(cnt);
         double Rb[9], tb[3], sb = NAN;
         fit = SIM3_NONE;
-        if (n >= 3.0) {
+        if (n >= 3.0) {                                                   // ref :430
             const double rn = 1.0 / n;
-            const double sc[3] = { wave_sum(s0) * rn, wave_sum(s1) * rn, wave_sum(s2) * rn };
-            const double dc[3] = { wave_sum(d0) * rn, wave_sum(d1) * rn, wave_sum(d2) * rn };
-            double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ssq = 0.0;
-            for (int64_t i = lane; i < N; i += 64) {
-                const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
-                const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
-                if (!ok) continue;
-                const double a0 = posb[i * 3] - sc[0], a1 = posb[i * 3 + 1] - sc[1], a2 = posb[i * 3 + 2] - sc[2];
-                const double b0 = z0 - dc[0], b1 = z1 - dc[1], b2 = z2 - dc[2];
-                H[0] += a0 * b0; H[1] += a0 * b1; H[2] += a0 * b2;
-                H[3] += a1 * b0; H[4] += a1 * b1; H[5] += a1 * b2;
-                H[6] += a2 * b0; H[7] += a2 * b1; H[8] += a2 * b2;
-                ssq += a0 * a0 + a1 * a1 + a2 * a2;
-            }
+            const double ma[3] = { wave_sum(Sa0) * rn, wave_sum(Sa1) * rn, wave_sum(Sa2) * rn };
+            const double mb[3] = { wave_sum(Sb0) * rn, wave_sum(Sb1) * rn, wave_sum(Sb2) * rn };
+            double H[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) H[k] = wave_sum(H[k]);
-            ssq = wave_sum(ssq);
+            for (int k = 0; k < 9; ++k) H[k] = wave_sum(Sab[k]) - n * ma[k / 3] * mb[k % 3];
+            const double ssq = fmax(0.0, wave_sum(Saa) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
+            const double sc[3] = { as0 + ma[0], as1 + ma[1], as2 + ma[2] }, dc[3] = { bs0 + mb[0], bs1 + mb[1], bs2 + mb[2] };
             fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);       // every lane redundantly (wave-uniform inputs)
         }
         Quat qn0; const bool q0ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, qn0);
@@ -170,6 +183,10 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
     Quat c_r; bool c_ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, c_r);
     double c_t = tsb[0];
     int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
+    int same_axis[3] = { -1, -1, -1 };                                   // wave-uniform: axis c repeats axis same_axis[c]
+    if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
+    if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
+    else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
 
     for (int64_t c0 = 0; c0 < N; c0 += 64) {
         const int64_t i = c0 + lane;
@@ -254,6 +271,8 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
         double Pf[3], Pm[3], kg[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            // axes with identical (P0, Q, R) have identical variance recursions: reuse the scan (default CONFIG: x == y)
+            if (c > 0 && same_axis[c] >= 0) { const int o = same_axis[c]; Pf[c] = Pf[o]; Pm[c] = Pm[o]; kg[c] = kg[o]; continue; }
             const double b0 = cfg.Qps[c] * dt, rr = cfg.Rm[c];
             double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
             if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }

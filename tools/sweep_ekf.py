@@ -27,7 +27,7 @@ for (nb, n, reps) in shapes:
     ctx.set_option("ekf_variant", 0)
     ms = timed(lambda: B.fuse_pipeline_batch(bt, out=o), reps)
     print(json.dumps({"B": nb, "N": n, "pipeline_ms": round(ms, 4), "Gposes_s": round(nb * n / ms / 1e6, 3), "alg_TBps": round(nb * n * 145 / ms / 1e9, 3)}), flush=True)
-    if nb * n <= 3e7:
+    if nb * n <= 2e8:
         bj = bt.to_layout(B.LAYOUT_TRAJ_MAJOR)
         oj = B.FusedPoses(bj.layout, nb, n, "cuda")
         ms = timed(lambda: B.ekf_fuse_batch(bj, out=oj), reps)
