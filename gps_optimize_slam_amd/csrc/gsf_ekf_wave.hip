@@ -210,13 +210,22 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
         const bool ok_pr = (lane == 0) ? c_ok : (((ok_mask >> (lane - 1)) & 1ull) != 0ull);
         const double dt = fmax(1e-6, t - t_pr);                          // ref :865
         const bool both_ok = ok_pr && ok;
-        const Quat r1i = quat_conj(r_pr);
-        Vec3 dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
-        Quat dq = quat_mul(r1i, r);
-        const bool move = stepping && both_ok;
-        dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
-        dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
-        if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
+        const u64 act_mask = __ballot(active);
+        // Fast path (every quaternion of the chunk and the carried one valid -- the normal case): the increments telescope,
+        //   dq_first * ... * dq_i = conj(r_carry) * r_i   and   R(q_{i-1}) R(r_{i-1})^-1 = R(Cq),  Cq = q_carry * conj(r_carry),
+        // so the orientation needs no scan and the predicted displacement is ONE rotation by the wave-uniform Cq
+        // (identical up to rounding: r conj(r) = 1 to 1 ulp for unit r).  Any invalid quaternion -> generic path below.
+        const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
+        Vec3 dpl{ 0.0, 0.0, 0.0 }; Quat dq{ 0.0, 0.0, 0.0, 1.0 };
+        if (!telescope) {                                                // calculate_relative_pose, ref :77-92
+            const Quat r1i = quat_conj(r_pr);
+            dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
+            dq = quat_mul(r1i, r);
+            const bool move = stepping && both_ok;
+            dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
+            dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
+            if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
+        }
         // ---- GNSS gate (ref :867-869) and the outage structure of the chunk as ballots
         const bool avail = stepping && vraw && !(isnan(z.x) || isnan(z.y) || isnan(z.z));
         const bool av = is_init ? vraw : avail;                          // "gnss available" flag of pose i (pose 0: raw mask, :848)
@@ -257,15 +266,24 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
         double wgt = 1.0;
         if (sharp && cfg.sharp_turn_steps > 1) wgt = 1.0 / (double)cfg.sharp_turn_steps;
 
-        // ---- orientation: inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
-        Quat D = dq;
-        const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
+        // ---- orientation (ref :708-709) and predicted displacement (ref :707)
+        Quat qi; Vec3 u;
+        if (telescope) {
+            const Quat Cq = quat_mul(cq, quat_conj(c_r));
+            qi = is_init ? cq : ekf_normalize(quat_mul(Cq, r));
+            u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
+            u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
+        } else {
+            // inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
+            Quat D = dq;
+            const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
 #define GSF_QSTAGE(CTRL, RM) { const Quat o = dpp<CTRL, RM>(QID, D); D = quat_mul(o, D); }
-        GSF_SCAN_STAGES(GSF_QSTAGE)
+            GSF_SCAN_STAGES(GSF_QSTAGE)
 #undef GSF_QSTAGE
-        const Quat qi = ekf_normalize(quat_mul(cq, D));                  // ref :708-709 (one normalisation per chunk)
-        const Quat q_prev = prev_lane(cq, qi);
-        const Vec3 u = quat_rotate(q_prev, dpl);                         // predicted displacement, ref :707
+            qi = ekf_normalize(quat_mul(cq, D));                         // one normalisation per chunk
+            const Quat q_prev = prev_lane(cq, qi);
+            u = quat_rotate(q_prev, dpl);
+        }
 
         // ---- variances: prefix composition of Moebius maps P -> (A P + Bm)/(Cm P + Dm) per axis (ref :712-713, :723-731)
         double Pf[3], Pm[3], kg[3];
