@@ -6,8 +6,8 @@
 A "step" is one pass of the hot path over one batch of synthetic, HBM-resident trajectories: one launch of the fused
 pipeline kernel (Umeyama fit on the valid rows -> Sim3 of pose 0 -> EKF predict/update + per-outage RTS), i.e. steps
 3-5 of the reference's main_process_gui (EKFGPSSLAM.py:1002-1010) for every trajectory of the batch.  Two mappings exist
-(DESIGN.md): wave-per-trajectory scans on the trajectory-major layout (default for c2: few, short tracks) and
-lane-per-trajectory recursion on the time-major layout (default for c3: huge batches); --layout overrides.
+(DESIGN.md): wave-per-trajectory scans on the trajectory-major layout (default; fastest at C2 and at C3) and
+lane-per-trajectory recursion on the time-major layout (--layout time).
 Workloads (BASELINE.json configs):
   c2 (default, configs[1]) 1k synthetic KITTI-04-length (271-pose) trajectories per GPU
   c3 (configs[2])          100k synthetic 1k-pose trajectories per GPU (HBM-bound regime)
@@ -86,7 +86,7 @@ def main():
     Bn, N = wl["B"], wl["N"]
     steps = args.steps if args.steps is not None else (200 if args.workload == "c2" else 10)
     warmup = args.warmup if args.warmup is not None else (20 if args.workload == "c2" else 2)
-    layout_name = args.layout or ("traj" if args.workload == "c2" else "time")
+    layout_name = args.layout or "traj"
     LAYOUT = B.LAYOUT_TRAJ_MAJOR if layout_name == "traj" else B.LAYOUT_TIME_MAJOR
     ctx = B.context()
     if args.ekf_variant is not None:

@@ -84,6 +84,22 @@ struct WaveArgs {
     int64_t B, N;
 };
 
+struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
+
+// pose i of one trajectory (clamped to the last pose for the idle lanes of the final chunk): one contiguous slab per array
+__device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, const double* __restrict__ posb, const double* __restrict__ quatb,
+                                              const double* __restrict__ gpsb, const uint8_t* __restrict__ valb, int64_t i, int64_t N)
+{
+    const int64_t il = i < N ? i : N - 1;
+    ChunkIn c;
+    c.t = tsb[il];
+    c.p = Vec3{ posb[il * 3], posb[il * 3 + 1], posb[il * 3 + 2] };
+    c.q = Quat{ quatb[il * 4], quatb[il * 4 + 1], quatb[il * 4 + 2], quatb[il * 4 + 3] };
+    c.z = Vec3{ gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2] };
+    c.v = valb[il];
+    return c;
+}
+
 template <bool PIPELINE>
 __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
@@ -188,19 +204,20 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
     if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
     else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
 
+    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     for (int64_t c0 = 0; c0 < N; c0 += 64) {
         const int64_t i = c0 + lane;
         const bool active = i < N;
         const bool is_init = (i == 0);
         const bool stepping = active && !is_init;
-        const int64_t il = active ? i : N - 1;
         const int L = (int)((N - c0 < 64) ? (N - c0 - 1) : 63);          // last active lane of this chunk
-        // ---- loads (one contiguous slab per array per chunk)
-        const double t = tsb[il];
-        const Vec3 p{ posb[il * 3], posb[il * 3 + 1], posb[il * 3 + 2] };
-        const Quat q{ quatb[il * 4], quatb[il * 4 + 1], quatb[il * 4 + 2], quatb[il * 4 + 3] };
-        const Vec3 z{ gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2] };
-        const bool vraw = valb[il] != 0;
+        // ---- this chunk's poses were loaded one iteration ago; issue the loads of the NEXT 64 poses now so that their
+        // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
+        const ChunkIn in = nxt;
+        if (c0 + 64 < N) nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);
+        const double t = in.t;
+        const Vec3 p = in.p; const Quat q = in.q; const Vec3 z = in.z;
+        const bool vraw = in.v != 0;
         // ---- calculate_relative_pose (ref :77-92) against the previous lane / the carry
         Quat r; const bool ok = quat_unit(q, r);
         const double t_pr = prev_lane(c_t, t);
