@@ -126,18 +126,29 @@ def main():
     for _ in range(warmup):
         step()
     D.barrier(dev); torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # HIP events on torch's current stream == the stream the kernels are launched on (B.context()).  One pair around the K
+    # launches: at C2 a launch is ~30 us, so per-launch event pairs would make the loop host-bound and pad the gaps.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(steps):
-        ev[k][0].record()                       # torch's current stream == the stream the kernel is launched on (B.context())
         launch()
-        ev[k][1].record()
         if world > 1:
             D._gather(out.pos, world, gather_bufs[0])
             D._gather(out.quat, world, gather_bufs[1])
+    ev1.record()
     torch.cuda.synchronize(); D.barrier(dev)
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    span_ms = ev0.elapsed_time(ev1)
+    if world == 1:
+        kern_ms = span_ms / steps               # back-to-back launches of the one kernel: span / K = average launch duration
+    else:                                       # with the collective in the loop, time the kernel alone in a second pass
+        torch.cuda.synchronize()
+        ev0.record()
+        for k in range(steps):
+            launch()
+        ev1.record(); torch.cuda.synchronize()
+        kern_ms = ev0.elapsed_time(ev1) / steps
     poses_per_step = world * Bn * N
     value = poses_per_step * steps / elapsed
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE

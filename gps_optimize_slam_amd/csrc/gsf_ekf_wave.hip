@@ -34,7 +34,11 @@ constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp(double old, double v)
 {
-    const long long o = __double_as_longlong(old), x = __double_as_longlong(v);
+    // `old` is tied to the destination: materialise it as ONE 64-bit register pair (a single v_mov_b64) instead of two
+    // 32-bit constant moves -- the empty asm pins the value in a VGPR pair before it is split into halves
+    double oo = old;
+    asm volatile("" : "+v"(oo));
+    const long long o = __double_as_longlong(oo), x = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
