@@ -85,6 +85,7 @@ SIGNATURES = {
     "gsf_is_sharp_turn_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp]),
     "gsf_ekf_process_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_f64), _i32, _vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp]),
     "gsf_rts_smoother_segment_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gsf_allgather_poses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64]),
     "gsf_transpose_to_time_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsf_transpose_to_traj_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsf_synth_batch_dev": (C.c_int, [_vp, _i32, C.c_uint64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -188,6 +188,13 @@ GSF_API int gsf_rts_smoother_segment_batch(gsf_ctx *ctx, const double *states_fi
                                            const double *covs_pred, const int64_t *offsets, int64_t B, double *states_smooth,
                                            double *covs_smooth);
 
+/* ---- multi-GPU collect: RCCL all-gather of the fused poses over xGMI ------------------------------- */
+/* All-gather `count` doubles per rank into recv[world][count], asynchronously on the context's stream, on a caller-provided
+   ncclComm_t (RCCL is resolved at run time).  mode 0 = one ncclAllGather; mode 1 = direct exchange (grouped
+   ncclSend/ncclRecv with every peer, `chunk_count` doubles at a time) so all point-to-point links carry traffic at once. */
+GSF_API int gsf_allgather_poses(gsf_ctx *ctx, void *nccl_comm, const double *send, double *recv, int64_t count, int32_t mode,
+                                int64_t chunk_count);
+
 /* ---- layout helpers + synthetic workload (bench / tests) ------------------------------------------ */
 /* [B][N][C] <-> [N][C][B] transposes of float64 (C = 1,3,4) and uint8 (C = 1) arrays, on device */
 GSF_API int gsf_transpose_to_time_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);

@@ -376,3 +376,26 @@ def test_extended_kalman_filter_class(E, golden, tag):
         assert abs(f.gnss_update_weight - float(g[f"ps_{tag}_w"][i])) < 1e-15
     with pytest.raises(ValueError):
         E.ExtendedKalmanFilter(np.zeros(2), np.zeros(4), E.CONFIG["ekf"])
+
+
+def test_rccl_allgather_wrapper_single_rank(B):
+    """gsf_allgather_poses on a 1-rank RCCL communicator (the box has one GPU): both modes must reproduce the send buffer."""
+    import ctypes as C
+    import os
+    import torch
+    from gps_optimize_slam_amd import _lib
+    L = _lib.load()
+    ctx = B.context()
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(torch.cuda.current_device())
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        send = torch.randn(100_003, dtype=torch.float64, device="cuda")
+        for mode, chunk in ((0, 0), (1, 0), (1, 4096)):
+            recv = torch.zeros_like(send)
+            _lib.check(L.gsf_allgather_poses(ctx.handle, comm, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), mode, chunk))
+            torch.cuda.synchronize()
+            assert torch.equal(send, recv), (mode, chunk)
+    finally:
+        rccl.ncclCommDestroy(comm)
