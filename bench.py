@@ -55,6 +55,24 @@ def cpu_baseline(B_mod, torch, N, target_seconds=10.0):
                       f"(dense 7x7 EKF+RTS + Umeyama), 1 thread of {os.cpu_count()} host cores"}
 
 
+def profiled_traffic(workload, kernel, grid_threads):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, produced by
+    tools/make_profiles.sh + tools/collect_profiles.py: separate --pmc runs of this same bench command; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as read).  None when no profile of this kernel/grid is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1])).get(workload, {})
+        key = f"{kernel} grid={grid_threads}"
+        if key in d:
+            return d[key]["hbm_bytes"], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,16 +172,19 @@ def main():
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     if layout_name == "traj":
-        kernel_name = "ekf_wave_kernel<PIPELINE>" if args.kernel == "pipeline" else "ekf_wave_kernel<EKF>"
+        kernel_name = "ekf_wave_kernel<true>" if args.kernel == "pipeline" else "ekf_wave_kernel<false>"      # <PIPELINE>
+        grid_threads = Bn * 64
     else:
-        kernel_name = "fuse_pipeline_kernel<TIME_MAJOR>" if args.kernel == "pipeline" else "ekf_fuse_kernel<TIME_MAJOR>"
+        kernel_name = "fuse_pipeline_kernel" if args.kernel == "pipeline" else "ekf_fuse_kernel"
+        grid_threads = ((Bn + 63) // 64) * 64
+    traffic, traffic_src = profiled_traffic(args.workload, kernel_name, grid_threads)
     result = {
         "metric": "fused poses/sec (whole node)", "value": value, "unit": "fused poses/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)" if layout_name == "traj" else "time-major SoA (lane-per-trajectory)", "step": args.kernel,
                    "parallelism": f"trajectory-sharded x{world}" + (", RCCL all-gather of fused poses per step" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+                     "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
     # ---- accuracy gate on this run: ATE RMSE of the GPU result vs the CPU oracle on a sample of the timed batch
     if rank == 0:

@@ -1,0 +1,45 @@
+"""Turn gpurun_out/profiles_raw/ (tools/make_profiles.sh) into the committed, judged artefacts under profiles/:
+   rNN_bench_default_kernel_stats.csv, rNN_bench_default_by_kernel_and_grid.csv, rNN_pmc_<workload>.txt, rNN_traffic.json
+usage: python tools/collect_profiles.py r01"""
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+raw, out = os.path.join(root, "gpurun_out", "profiles_raw"), os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+ks = glob.glob(raw + "/trace_bench_default/**/*_kernel_stats.csv", recursive=True)
+kt = glob.glob(raw + "/trace_bench_default/**/*_kernel_trace.csv", recursive=True)
+if ks:
+    shutil.copy(ks[0], f"{out}/{tag}_bench_default_kernel_stats.csv")
+if kt:
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), kt[0], f"{out}/{tag}_bench_default_by_kernel_and_grid.csv"])
+if os.path.exists(raw + "/bench_default.json"):
+    shutil.copy(raw + "/bench_default.json", f"{out}/{tag}_bench_default_under_rocprof.json")
+traffic = {}
+pat = re.compile(r"(ekf_wave_kernel<\w+>|fuse_pipeline_kernel|ekf_fuse_kernel)")
+for wl in ("c2", "c3"):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{raw}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            m = pat.search(row["Kernel_Name"])
+            if m:
+                per[m.group(1) + " grid=" + row.get("Grid_Size", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    lines = []
+    for k in sorted(per):
+        lines.append(f"== {k}")
+        for c in sorted(per[k]):
+            v = per[k][c]
+            lines.append(f"   {c:24s} mean/dispatch {sum(v) / len(v):14.6g}   ({len(v)} dispatches)")
+        fs, ws = per[k].get("FETCH_SIZE"), per[k].get("WRITE_SIZE")
+        if fs and ws:
+            # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
+            # coalesced streaming read -> doubled before it is compared with a byte count; WRITE_SIZE is exact
+            fetch = 2.0 * 1024.0 * sum(fs) / len(fs)
+            write = 1024.0 * sum(ws) / len(ws)
+            traffic.setdefault(wl, {})[k] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
+                                            "FETCH_SIZE_raw_KiB": sum(fs) / len(fs), "WRITE_SIZE_raw_KiB": sum(ws) / len(ws)}
+            lines.append(f"   -> HBM traffic per launch: fetch {fetch / 1e9:.3f} GB (2 x FETCH_SIZE, gfx950 correction) + write {write / 1e9:.3f} GB")
+    if lines:
+        open(f"{out}/{tag}_pmc_{wl}.txt", "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+print(open(f"{out}/{tag}_traffic.json").read())

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root: rocprofv3 evidence for the bench's kernels.
+#   1. kernel trace + stats of the DEFAULT bench command (python3 bench.py)
+#   2. PMC passes (separate runs: gpurun forbids mixing --pmc with trace domains) for HBM traffic and issue mix
+# Outputs under gpurun_out/profiles_raw/; tools/collect_profiles.py turns them into the committed profiles/*.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_raw
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench_default -- python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "trace failed"
+for wl in c2 c3; do
+  for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
+    n=$(echo $p | cut -d" " -f1)
+    timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload $wl --no-extra --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
+  done
+done
+ls $OUT
