@@ -228,6 +228,9 @@ extern "C" int gsf_ekf_fuse_batch_dev(gsf_ctx* ctx, int32_t layout, const double
         }
     } else if (ctx->ekf_variant == 9) {
         GSF_LAUNCH_EKF(GSF_LAYOUT_TRAJ_MAJOR, 2, 2);                   // lane-per-trajectory on strided rows (comparison only)
+    } else if (use_block_kernel(ctx, B, N)) {
+        return launch_ekf_block(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr,
+                                pos_out, quat_out, status);            // wave-per-chunk scans (gsf_ekf_block.hip)
     } else {
         return launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr,
                                pos_out, quat_out, status);             // wave-per-trajectory scans (gsf_ekf_wave.hip)
@@ -256,6 +259,8 @@ extern "C" int gsf_fuse_pipeline_batch_dev(gsf_ctx* ctx, int32_t layout, const d
     else if (ctx->ekf_variant == 9)
         hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TRAJ_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
                            R, t, s, pos_out, quat_out, status);
+    else if (use_block_kernel(ctx, B, N))
+        return launch_ekf_block(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
     else
         return launch_ekf_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
     GSF_HIP(hipGetLastError());

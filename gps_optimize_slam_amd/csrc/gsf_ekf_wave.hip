@@ -16,399 +16,16 @@
 // Arithmetic differs from the serial form only in rounding order (quaternion renormalisation once per chunk instead of
 // every step, Moebius instead of Joseph variance update, local coordinates per chunk): observed |dp| ~1e-9 m against
 // the 1e-6 m gate; the tests compare against the dense-7x7 CPU oracle.
-#include "gsf_internal.hpp"
+#include "gsf_wave_common.hpp"
 
 using namespace gsf;
 
 namespace {
 
-typedef unsigned long long u64;
-
-// ---- cross-lane movement.  The scans run on DPP (data-parallel-primitive) operand routing -- a VALU move, no LDS round
-// trip: row_shr:1/2/4/8 inside the four 16-lane rows, then row_bcast:15 (rows 1,3 <- lane 15 of the row before) and
-// row_bcast:31 (rows 2,3 <- lane 31).  Lanes without a source keep `old`, which is passed as the IDENTITY of the scanned
-// monoid, so every stage is an unconditional "other o mine".  ds_bpermute (__shfl) is kept only for per-lane indices.
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
-constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp(double old, double v)
-{
-    // `old` is tied to the destination: materialise it as ONE 64-bit register pair (a single v_mov_b64) instead of two
-    // 32-bit constant moves -- the empty asm pins the value in a VGPR pair before it is split into halves
-    double oo = old;
-    asm volatile("" : "+v"(oo));
-    const long long o = __double_as_longlong(oo), x = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ Quat dpp(const Quat& old, const Quat& v)
-{
-    return Quat{ dpp<CTRL, ROW_MASK>(old.x, v.x), dpp<CTRL, ROW_MASK>(old.y, v.y), dpp<CTRL, ROW_MASK>(old.z, v.z), dpp<CTRL, ROW_MASK>(old.w, v.w) };
-}
-// value of the previous lane; lane 0 receives `carry`
-__device__ __forceinline__ double prev_lane(double carry, double v) { return dpp<DPP_WAVE_SHR1, 0xf>(carry, v); }
-__device__ __forceinline__ Quat prev_lane(const Quat& c, const Quat& v) { return dpp<DPP_WAVE_SHR1, 0xf>(c, v); }
-// wave-uniform source lane -> v_readlane (result lives in SGPRs)
-__device__ __forceinline__ double lane_bcast(double v, int src)
-{
-    const long long x = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)x, src), hi = __builtin_amdgcn_readlane((int)(x >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ Quat lane_bcast(const Quat& q, int s) { return Quat{ lane_bcast(q.x, s), lane_bcast(q.y, s), lane_bcast(q.z, s), lane_bcast(q.w, s) }; }
-__device__ __forceinline__ Vec3 lane_bcast(const Vec3& v, int s) { return Vec3{ lane_bcast(v.x, s), lane_bcast(v.y, s), lane_bcast(v.z, s) }; }
-__device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, src, 64); }          // per-lane source index
-#define GSF_SCAN_STAGES(STAGE) STAGE(DPP_ROW_SHR1, 0xf) STAGE(DPP_ROW_SHR2, 0xf) STAGE(DPP_ROW_SHR4, 0xf) STAGE(DPP_ROW_SHR8, 0xf) \
-                               STAGE(DPP_ROW_BCAST15, 0xa) STAGE(DPP_ROW_BCAST31, 0xc)
-// sum over the wave: inclusive DPP scan, total read from lane 63 (wave-uniform result)
-__device__ __forceinline__ double wave_sum(double v)
-{
-#define GSF_SUMSTAGE(CTRL, RM) { v += dpp<CTRL, RM>(0.0, v); }
-    GSF_SCAN_STAGES(GSF_SUMSTAGE)
-#undef GSF_SUMSTAGE
-    return lane_bcast(v, 63);
-}
-// bits lo..hi (inclusive) of a 64-bit mask; empty if lo > hi
-__device__ __forceinline__ u64 bits(int lo, int hi)
-{
-    if (lo > hi) return 0ull;
-    const u64 upto_hi = (hi >= 63) ? ~0ull : ((1ull << (hi + 1)) - 1ull);
-    const u64 below_lo = (lo <= 0) ? 0ull : ((1ull << lo) - 1ull);
-    return upto_hi & ~below_lo;
-}
-
-struct WaveArgs {
-    const double* ts; const double* pos; const double* quat; const double* gps; const uint8_t* valid;
-    const double* init_pos; const double* init_quat;
-    double* R; double* t; double* s;              // pipeline outputs (may be null)
-    double* pos_out; double* quat_out; int32_t* status;
-    int64_t B, N;
-};
-
-struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
-
-// pose i of one trajectory (clamped to the last pose for the idle lanes of the final chunk): one contiguous slab per array
-__device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, const double* __restrict__ posb, const double* __restrict__ quatb,
-                                              const double* __restrict__ gpsb, const uint8_t* __restrict__ valb, int64_t i, int64_t N)
-{
-    const int64_t il = i < N ? i : N - 1;
-    ChunkIn c;
-    c.t = tsb[il];
-    c.p = Vec3{ posb[il * 3], posb[il * 3 + 1], posb[il * 3 + 2] };
-    c.q = Quat{ quatb[il * 4], quatb[il * 4 + 1], quatb[il * 4 + 2], quatb[il * 4 + 3] };
-    c.z = Vec3{ gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2] };
-    c.v = valb[il];
-    return c;
-}
-
 template <bool PIPELINE>
 __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
-    const int lane = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    const int64_t N = a.N;
-    const double* __restrict__ tsb = a.ts + b * N;
-    const double* __restrict__ posb = a.pos + b * N * 3;
-    const double* __restrict__ quatb = a.quat + b * N * 4;
-    const double* __restrict__ gpsb = a.gps + b * N * 3;
-    const uint8_t* __restrict__ valb = a.valid + b * N;
-    double* __restrict__ pob = a.pos_out + b * N * 3;
-    double* __restrict__ qob = a.quat_out + b * N * 4;
-
-    // ------------------------------------------------------------------ initial pose
-    Vec3 p0; Quat q0;
-    int32_t fit = 0;
-    if (PIPELINE) {
-        // K2 on the rows with valid, finite GNSS, ONE pass: moments of the data shifted by pose 0 / the first finite fix
-        // (|shifted| <= track length, so the raw-moment form H = Sab - n ma mb^T loses nothing at UTM magnitudes), then K3
-        // of pose 0.  Sums are per-lane partials + a DPP wave reduction.
-        const double as0 = posb[0], as1 = posb[1], as2 = posb[2];
-        double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
-        {   // shift for the GNSS side: the first valid finite fix of the track (wave-uniform)
-            bool found = false;
-            for (int64_t c0 = 0; c0 < N && !found; c0 += 64) {
-                const int64_t i = c0 + lane;
-                bool ok = false; double z0 = 0, z1 = 0, z2 = 0;
-                if (i < N) { z0 = gpsb[i * 3]; z1 = gpsb[i * 3 + 1]; z2 = gpsb[i * 3 + 2]; ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2)); }
-                const u64 m = __ballot(ok);
-                if (m != 0ull) { const int f = __ffsll((long long)m) - 1; bs0 = lane_bcast(z0, f); bs1 = lane_bcast(z1, f); bs2 = lane_bcast(z2, f); found = true; }
-            }
-        }
-        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
-        double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int64_t i = lane; i < N; i += 64) {
-            const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
-            const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
-            if (!ok) continue;
-            const double a0 = posb[i * 3] - as0, a1 = posb[i * 3 + 1] - as1, a2 = posb[i * 3 + 2] - as2;
-            const double b0 = z0 - bs0, b1 = z1 - bs1, b2 = z2 - bs2;
-            cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
-            Saa += a0 * a0 + a1 * a1 + a2 * a2;
-            Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
-            Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
-            Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
-        }
-        const double n = wave_sum(cnt);
-        double Rb[9], tb[3], sb = NAN;
-        fit = SIM3_NONE;
-        if (n >= 3.0) {                                                   // ref :430
-            const double rn = 1.0 / n;
-            const double ma[3] = { wave_sum(Sa0) * rn, wave_sum(Sa1) * rn, wave_sum(Sa2) * rn };
-            const double mb[3] = { wave_sum(Sb0) * rn, wave_sum(Sb1) * rn, wave_sum(Sb2) * rn };
-            double H[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) H[k] = wave_sum(Sab[k]) - n * ma[k / 3] * mb[k % 3];
-            const double ssq = fmax(0.0, wave_sum(Saa) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
-            const double sc[3] = { as0 + ma[0], as1 + ma[1], as2 + ma[2] }, dc[3] = { bs0 + mb[0], bs1 + mb[1], bs2 + mb[2] };
-            fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);       // every lane redundantly (wave-uniform inputs)
-        }
-        Quat qn0; const bool q0ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, qn0);
-        if (fit == SIM3_NONE || !q0ok) {                                  // wave-uniform
-            for (int64_t i = lane; i < N; i += 64) {
-                pob[i * 3] = NAN; pob[i * 3 + 1] = NAN; pob[i * 3 + 2] = NAN;
-                qob[i * 4] = NAN; qob[i * 4 + 1] = NAN; qob[i * 4 + 2] = NAN; qob[i * 4 + 3] = NAN;
-            }
-            if (lane == 0) {
-                for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
-                a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
-                if (a.status) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
-            }
-            return;
-        }
-        if (lane == 0) {
-            for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
-            a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
-        }
-        const double x = posb[0], y = posb[1], z = posb[2];
-        p0 = Vec3{ sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + tb[0], sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + tb[1],
-                   sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + tb[2] };   // ref :464
-        q0 = quat_mul(quat_from_matrix(Rb), qn0);                        // ref :465-466
-    } else {
-        p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
-        q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };
-    }
-
-    // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
-    Quat cq = ekf_normalize(q0);                                         // ref :842, :683
-    Vec3 cp = p0;
-    double cP[3] = { cfg.P0[0], cfg.P0[1], cfg.P0[2] };
-    bool c_prev_avail = valb[0] != 0;                                    // ref :848 (raw mask)
-    int64_t c_ostart = 0;                                                // ref :861-862
-    bool c_seg_sharp = false;
-    double cPos[3] = { cP[0], cP[1], cP[2] };                            // P_f at the first pose of the open outage
-    Vec3 c_po{ posb[0], posb[1], posb[2] };
-    Quat c_r; bool c_ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, c_r);
-    double c_t = tsb[0];
-    int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
-    int same_axis[3] = { -1, -1, -1 };                                   // wave-uniform: axis c repeats axis same_axis[c]
-    if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
-    if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
-    else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
-
-    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
-    for (int64_t c0 = 0; c0 < N; c0 += 64) {
-        const int64_t i = c0 + lane;
-        const bool active = i < N;
-        const bool is_init = (i == 0);
-        const bool stepping = active && !is_init;
-        const int L = (int)((N - c0 < 64) ? (N - c0 - 1) : 63);          // last active lane of this chunk
-        // ---- this chunk's poses were loaded one iteration ago; issue the loads of the NEXT 64 poses now so that their
-        // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
-        const ChunkIn in = nxt;
-        if (c0 + 64 < N) nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);
-        const double t = in.t;
-        const Vec3 p = in.p; const Quat q = in.q; const Vec3 z = in.z;
-        const bool vraw = in.v != 0;
-        // ---- calculate_relative_pose (ref :77-92) against the previous lane / the carry
-        Quat r; const bool ok = quat_unit(q, r);
-        const double t_pr = prev_lane(c_t, t);
-        const Vec3 p_pr{ prev_lane(c_po.x, p.x), prev_lane(c_po.y, p.y), prev_lane(c_po.z, p.z) };
-        const Quat r_pr = prev_lane(c_r, r);
-        const u64 ok_mask = __ballot(ok);
-        const bool ok_pr = (lane == 0) ? c_ok : (((ok_mask >> (lane - 1)) & 1ull) != 0ull);
-        const double dt = fmax(1e-6, t - t_pr);                          // ref :865
-        const bool both_ok = ok_pr && ok;
-        const u64 act_mask = __ballot(active);
-        // Fast path (every quaternion of the chunk and the carried one valid -- the normal case): the increments telescope,
-        //   dq_first * ... * dq_i = conj(r_carry) * r_i   and   R(q_{i-1}) R(r_{i-1})^-1 = R(Cq),  Cq = q_carry * conj(r_carry),
-        // so the orientation needs no scan and the predicted displacement is ONE rotation by the wave-uniform Cq
-        // (identical up to rounding: r conj(r) = 1 to 1 ulp for unit r).  Any invalid quaternion -> generic path below.
-        const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
-        Vec3 dpl{ 0.0, 0.0, 0.0 }; Quat dq{ 0.0, 0.0, 0.0, 1.0 };
-        if (!telescope) {                                                // calculate_relative_pose, ref :77-92
-            const Quat r1i = quat_conj(r_pr);
-            dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
-            dq = quat_mul(r1i, r);
-            const bool move = stepping && both_ok;
-            dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
-            dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
-            if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
-        }
-        // ---- GNSS gate (ref :867-869) and the outage structure of the chunk as ballots
-        const bool avail = stepping && vraw && !(isnan(z.x) || isnan(z.y) || isnan(z.z));
-        const bool av = is_init ? vraw : avail;                          // "gnss available" flag of pose i (pose 0: raw mask, :848)
-        const u64 a_mask = __ballot(active && av);
-        const bool ap = (lane == 0) ? (is_init ? true : c_prev_avail) : (((a_mask >> (lane - 1)) & 1ull) != 0ull);
-        const bool starts = active && !av && ap;                         // outage begins at this pose (ref :875-877; pose 0: :861)
-        const bool recovers = stepping && av && !ap;                     // ref :879
-        const bool outpair = stepping && !av && !ap;                     // poses i-1 and i both inside the outage
-        const u64 start_mask = __ballot(starts), rec_mask = __ballot(recovers), pair_mask = __ballot(outpair);
-        if (start_mask != 0ull) status |= ST_HAD_OUTAGE;
-        // is_sharp_turn_in_segment (ref :808-826): pair (i-1, i) exceeds the yaw-rate threshold (or has a bad quaternion)
-        u64 f_mask = 0ull;
-        if (pair_mask != 0ull) {
-            bool f = false;
-            if (outpair && t > t_pr) f = !both_ok || yaw_rate_exceeds(r_pr, r, t - t_pr, cfg.yaw_thr_rad);
-            f_mask = __ballot(f);
-        }
-        // recovery decision per recovering lane (ref :879-894)
-        bool sharp = false;
-        if (recovers) {
-            const u64 sm = start_mask & bits(0, lane - 1);
-            int64_t s_glob; bool seg;
-            if (sm != 0ull) {
-                const int s = 63 - __clzll((long long)sm);
-                s_glob = c0 + s;
-                seg = (f_mask & bits(s + 1, lane - 1)) != 0ull;
-            } else {
-                s_glob = c_ostart;
-                seg = c_seg_sharp || (f_mask & bits(0, lane - 1)) != 0ull;
-            }
-            sharp = (i - s_glob >= 2) && seg;
-        }
-        const u64 sharp_mask = __ballot(sharp);
-        const u64 rts_mask = rec_mask & ~sharp_mask;                     // recoveries that run the RTS back-pass
-        if (sharp_mask != 0ull) status |= ST_SHARP_TURN;
-        if (rts_mask != 0ull) status |= ST_RTS_APPLIED;
-        // one-step blend weight on a sharp-turn recovery (ref :752-768, Q7): 1/eff if eff > 1, else a hard update
-        double wgt = 1.0;
-        if (sharp && cfg.sharp_turn_steps > 1) wgt = 1.0 / (double)cfg.sharp_turn_steps;
-
-        // ---- orientation (ref :708-709) and predicted displacement (ref :707)
-        Quat qi; Vec3 u;
-        if (telescope) {
-            const Quat Cq = quat_mul(cq, quat_conj(c_r));
-            qi = is_init ? cq : ekf_normalize(quat_mul(Cq, r));
-            u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
-            u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
-        } else {
-            // inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
-            Quat D = dq;
-            const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
-#define GSF_QSTAGE(CTRL, RM) { const Quat o = dpp<CTRL, RM>(QID, D); D = quat_mul(o, D); }
-            GSF_SCAN_STAGES(GSF_QSTAGE)
-#undef GSF_QSTAGE
-            qi = ekf_normalize(quat_mul(cq, D));                         // one normalisation per chunk
-            const Quat q_prev = prev_lane(cq, qi);
-            u = quat_rotate(q_prev, dpl);
-        }
-
-        // ---- variances: prefix composition of Moebius maps P -> (A P + Bm)/(Cm P + Dm) per axis (ref :712-713, :723-731)
-        double Pf[3], Pm[3], kg[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            // axes with identical (P0, Q, R) have identical variance recursions: reuse the scan (default CONFIG: x == y)
-            if (c > 0 && same_axis[c] >= 0) { const int o = same_axis[c]; Pf[c] = Pf[o]; Pm[c] = Pm[o]; kg[c] = kg[o]; continue; }
-            const double b0 = cfg.Qps[c] * dt, rr = cfg.Rm[c];
-            double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
-            if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
-            // mine (later) o other (earlier); lanes without a source see the identity map (1,0;0,1)
-#define GSF_MSTAGE(CTRL, RM) {                                                                                              \
-                const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp<CTRL, RM>(0.0, Bm), oC = dpp<CTRL, RM>(0.0, Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
-                const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
-                A = nA; Bm = nB; Cm = nC; Dm = nD; }
-            GSF_SCAN_STAGES(GSF_MSTAGE)
-#undef GSF_MSTAGE
-            Pf[c] = (A * cP[c] + Bm) * fast_rcp(Cm * cP[c] + Dm);        // P_f[i]
-            Pm[c] = prev_lane(cP[c], Pf[c]) + b0;                        // P_p[i]
-            kg[c] = Pm[c] * fast_rcp(Pm[c] + rr);                        // Kalman gain if the fix is used
-        }
-
-        // ---- positions: prefix composition of affine maps x -> al x + be in chunk-local coordinates (x = p - p_carry)
-        const double uu[3] = { u.x, u.y, u.z }, zl[3] = { z.x - cp.x, z.y - cp.y, z.z - cp.z };
-        double xl[3], dcorr[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double kw = kg[c] * wgt;
-            double al = avail ? (1.0 - kw) : 1.0;
-            double be = avail ? ((1.0 - kw) * uu[c] + kw * zl[c]) : uu[c];
-#define GSF_ASTAGE(CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al), ob = dpp<CTRL, RM>(0.0, be); be = al * ob + be; al = al * oa; }
-            GSF_SCAN_STAGES(GSF_ASTAGE)
-#undef GSF_ASTAGE
-            xl[c] = be;                                                  // x_i (the carry is x = 0)
-            dcorr[c] = xl[c] - (prev_lane(0.0, be) + uu[c]);             // x_f[i] - x_p[i] (non-zero only where a fix was used)
-        }
-
-        // ---- per-outage RTS (ref :906-922, :777-803).  Inside an outage x_f = x_p and P_f = P_p, so the gain product
-        // telescopes: x_s[k] = x_f[k] + (P_f[k] / P_p[r]) (x_f[r] - x_p[r]) for k in [start, r-1], r = the recovery pose.
-        double xo[3] = { xl[0], xl[1], xl[2] };                          // what is written out (filter state stays xl)
-        if (rts_mask != 0ull) {
-            const u64 later = rec_mask & ~bits(0, lane);                 // recoveries after this lane
-            const int rl = later != 0ull ? __ffsll((long long)later) - 1 : 0;
-            const bool in_run = active && !av && later != 0ull && (((rts_mask >> rl) & 1ull) != 0ull);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double dr = shidx(dcorr[c], rl), pr = shidx(Pm[c], rl);
-                if (in_run) xo[c] = xl[c] + Pf[c] * fast_rcp(pr) * dr;
-            }
-            // outage carried in from earlier chunks and closed here by an RTS recovery: fix the rows already written
-            if (!c_prev_avail) {
-                const int r1 = __ffsll((long long)rec_mask) - 1;         // first recovery of the chunk closes the carried run
-                if ((rts_mask >> r1) & 1ull) {
-                    const double dr[3] = { lane_bcast(dcorr[0], r1), lane_bcast(dcorr[1], r1), lane_bcast(dcorr[2], r1) };
-                    const double ipr[3] = { fast_rcp(lane_bcast(Pm[0], r1)), fast_rcp(lane_bcast(Pm[1], r1)), fast_rcp(lane_bcast(Pm[2], r1)) };
-                    double acc = 0.0;                                    // sum of dt over (ostart, k]
-                    for (int64_t k0 = (c_ostart / 64) * 64; k0 < c0; k0 += 64) {
-                        const int64_t k = k0 + lane;
-                        const double tk = tsb[k];
-                        const double tkp = prev_lane((k0 > 0) ? tsb[k0 - 1] : tk, tk);
-                        double dsum = (k > c_ostart) ? fmax(1e-6, tk - tkp) : 0.0;
-#define GSF_SSTAGE(CTRL, RM) { dsum += dpp<CTRL, RM>(0.0, dsum); }
-                        GSF_SCAN_STAGES(GSF_SSTAGE)
-#undef GSF_SSTAGE
-                        const double tot = lane_bcast(dsum, 63);
-                        if (k >= c_ostart) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const double Pk = cPos[c] + cfg.Qps[c] * (acc + dsum);      // P_f[k] inside the outage
-                                pob[k * 3 + c] += Pk * ipr[c] * dr[c];
-                            }
-                        }
-                        acc += tot;
-                    }
-                }
-            }
-        }
-
-        // ---- stores
-        if (active) {
-            pob[i * 3] = cp.x + xo[0]; pob[i * 3 + 1] = cp.y + xo[1]; pob[i * 3 + 2] = cp.z + xo[2];
-            qob[i * 4] = qi.x; qob[i * 4 + 1] = qi.y; qob[i * 4 + 2] = qi.z; qob[i * 4 + 3] = qi.w;
-        }
-
-        // ---- carry to the next 64 poses (from the last active lane L)
-        const bool open = ((a_mask >> L) & 1ull) == 0ull;                // the chunk ends inside an outage
-        if (open) {
-            const u64 sm = start_mask & bits(0, L);
-            if (sm != 0ull) {
-                const int s = 63 - __clzll((long long)sm);
-                c_ostart = c0 + s;
-                c_seg_sharp = (f_mask & bits(s + 1, L)) != 0ull;
-                cPos[0] = lane_bcast(Pf[0], s); cPos[1] = lane_bcast(Pf[1], s); cPos[2] = lane_bcast(Pf[2], s);
-            } else {
-                c_seg_sharp = c_seg_sharp || (f_mask & bits(0, L)) != 0ull;
-            }
-        }
-        c_prev_avail = !open;
-        cq = lane_bcast(qi, L);
-        cp = Vec3{ cp.x + lane_bcast(xl[0], L), cp.y + lane_bcast(xl[1], L), cp.z + lane_bcast(xl[2], L) };
-        cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
-        c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
-    }
-    if (lane == 0 && a.status) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
+    wave_serial_body<PIPELINE>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 EkfConfig to_core(const gsf_ekf_config* c)

@@ -52,4 +52,17 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
 
+// wave-per-chunk / block-per-trajectory variant for small batches of short tracks (gsf_ekf_block.hip), N <= 1024
+int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
+                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
+// trajectory-major dispatch.  Measured on MI355X: the chunk-parallel block kernel is SLOWER than the serial
+// wave kernel even at C2 (1 000 x 271: 29 us vs 22 us for K4) -- 1 000 waves already occupy all 1 024 SIMDs and the serial kernel
+// is ~60 % issue-bound, so extra waves only add carry-composition / barrier work.  It is therefore opt-in (ekf_variant 8 / 6).
+inline bool use_block_kernel(const gsf_ctx* ctx, int64_t B, int64_t N)
+{
+    (void)B;
+    return N <= 1024 && (ctx->ekf_variant == 8 || ctx->ekf_variant == 6);
+}
+
 }  // namespace gsf
