@@ -90,19 +90,19 @@ __device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, co
 }
 
 
-// One wave walks trajectory `b` 64 poses at a time (serial over chunks, scans inside a chunk).
+// Initial pose of trajectory b: either the caller's Sim3-aligned pose 0, or (PIPELINE) the Umeyama fit on the rows with valid
+// finite GNSS + Sim3 of pose 0.  Returns false (after writing NaN outputs / status) when the fit is None or pose 0's quaternion
+// is invalid -- wave-uniformly.
 template <bool PIPELINE>
-__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane)
+__device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b, const int lane, Vec3& p0_out, Quat& q0_out, int32_t& fit_out)
 {
     const int64_t N = a.N;
-    const double* __restrict__ tsb = a.ts + b * N;
     const double* __restrict__ posb = a.pos + b * N * 3;
     const double* __restrict__ quatb = a.quat + b * N * 4;
     const double* __restrict__ gpsb = a.gps + b * N * 3;
     const uint8_t* __restrict__ valb = a.valid + b * N;
     double* __restrict__ pob = a.pos_out + b * N * 3;
     double* __restrict__ qob = a.quat_out + b * N * 4;
-
     // ------------------------------------------------------------------ initial pose
     Vec3 p0; Quat q0;
     int32_t fit = 0;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
                 a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
                 if (a.status) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
             }
-            return;
+            return false;
         }
         if (lane == 0) {
             for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
@@ -175,6 +175,26 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
         q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };
     }
+
+    p0_out = p0; q0_out = q0; fit_out = fit;
+    return true;
+}
+
+// One wave walks trajectory `b` 64 poses at a time (serial over chunks, scans inside a chunk).
+template <bool PIPELINE>
+__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane)
+{
+    const int64_t N = a.N;
+    const double* __restrict__ tsb = a.ts + b * N;
+    const double* __restrict__ posb = a.pos + b * N * 3;
+    const double* __restrict__ quatb = a.quat + b * N * 4;
+    const double* __restrict__ gpsb = a.gps + b * N * 3;
+    const uint8_t* __restrict__ valb = a.valid + b * N;
+    double* __restrict__ pob = a.pos_out + b * N * 3;
+    double* __restrict__ qob = a.quat_out + b * N * 4;
+
+    Vec3 p0; Quat q0; int32_t fit = 0;
+    if (!wave_prelude<PIPELINE>(a, b, lane, p0, q0, fit)) return;
 
     // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
     Quat cq = ekf_normalize(q0);                                         // ref :842, :683

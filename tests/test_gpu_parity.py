@@ -257,16 +257,18 @@ def test_pipeline_batch_vs_oracle(B, orc, layout):
         assert (st[b] & 0xff) == sto
 
 
+@pytest.mark.parametrize("variant", [8, 5])
 @pytest.mark.parametrize("N", [271, 1000, 64, 130])
-def test_block_kernel_variant_vs_oracle(B, orc, N):
-    """The chunk-parallel block kernel (opt-in, ekf_variant 8) against the oracle, incl. the generic bad-quaternion path."""
+def test_experimental_kernel_variants_vs_oracle(B, orc, N, variant):
+    """The opt-in trajectory-major variants -- chunk-parallel block kernel (ekf_variant 8) and two-poses-per-lane wave kernel
+    (ekf_variant 5) -- against the oracle, incl. the generic bad-quaternion path."""
     import torch
     nb = 300
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=21)
     batch.quat[5, N // 2] = 0.0                      # one invalid quaternion -> generic (non-telescoped) path for track 5
     batch.quat[9, 0] = 0.0
     ctx = B.context()
-    ctx.set_option("ekf_variant", 8)
+    ctx.set_option("ekf_variant", variant)
     try:
         out = B.ekf_fuse_batch(batch)
         outp, R, t, s = B.fuse_pipeline_batch(batch)

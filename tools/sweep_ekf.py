@@ -34,7 +34,7 @@ for (nb, n, reps) in shapes:
         print(json.dumps({"B": nb, "N": n, "wave_ekf_ms": round(ms, 4), "Gposes_s": round(nb * n / ms / 1e6, 3), "alg_TBps": round(nb * n * 145 / ms / 1e9, 3)}), flush=True)
         ms = timed(lambda: B.fuse_pipeline_batch(bj, out=oj), reps)
         print(json.dumps({"B": nb, "N": n, "wave_pipeline_ms": round(ms, 4), "Gposes_s": round(nb * n / ms / 1e6, 3), "alg_TBps": round(nb * n * 145 / ms / 1e9, 3)}), flush=True)
-        for v, nm in ((7, "serialwave"), (8, "block"), (6, "block256reg")):
+        for v, nm in ((0, "wave_ppl1"), (5, "wave_ppl2"), (8, "block")):
             ctx.set_option("ekf_variant", v)
             ms_e = timed(lambda: B.ekf_fuse_batch(bj, out=oj), reps)
             ms_p = timed(lambda: B.fuse_pipeline_batch(bj, out=oj), reps)
