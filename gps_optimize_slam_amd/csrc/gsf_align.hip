@@ -1,0 +1,225 @@
+// gsf_align.hip -- GNSS positions interpolated onto the SLAM stamps: dynamic_time_alignment (EKFGPSSLAM.py:325-387), the
+// step right before both the Sim3 fit and the EKF (SURVEY 8f "next-1").
+//
+// One 64-lane workgroup per trajectory, the GNSS track staged in LDS (t, y[3], second derivatives M[3]: 56 B per fix):
+//   1. sort by stamp if needed (rank sort, stable by input order) and keep the first of equal stamps (np.unique, :339-346);
+//   2. split at gaps > max_gps_gap_threshold (:348-352); a segment needs >= 2 fixes and stamps increasing by > 1e-9 (:364);
+//   3. >= 4 fixes: not-a-knot cubic spline (scipy interp1d(kind='cubic'), :362/:368) -- the tridiagonal system for the knot
+//      second derivatives is solved by lanes 0..2 (one per component, Thomas algorithm); 2-3 fixes: linear;
+//   4. every SLAM stamp inside [t0-1e-9, t1+1e-9] (:372-373) is evaluated by its own lane (binary search of the interval);
+//      stamps outside [t0, t1] get NaN like interp1d(bounds_error=False, fill_value=nan); valid = all three finite (:377-379).
+// The clock-offset estimate of :336 is identically 0 and is not computed.
+#include "gsf_internal.hpp"
+
+using namespace gsf;
+
+namespace {
+
+constexpr int ALIGN_THREADS = 64;
+
+__global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double* __restrict__ slam_t, const int64_t* __restrict__ slam_off,
+                                                                    const double* __restrict__ gps_t, const double* __restrict__ gps_p,
+                                                                    const int64_t* __restrict__ gps_off, double max_gap, int max_g,
+                                                                    double* __restrict__ aligned, uint8_t* __restrict__ valid,
+                                                                    int32_t* __restrict__ status)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t s0 = slam_off[b], ns = slam_off[b + 1] - s0;
+    const int64_t g0 = gps_off[b];
+    const int ng = (int)(gps_off[b + 1] - g0);
+    const double* st = slam_t + s0;
+    double* al = aligned + s0 * 3;
+    uint8_t* va = valid + s0;
+    for (int64_t i = lane; i < ns; i += ALIGN_THREADS) { al[i * 3] = NAN; al[i * 3 + 1] = NAN; al[i * 3 + 2] = NAN; va[i] = 0; }   // :331
+    if (status && lane == 0) status[b] = 0;
+    if (ns == 0 || ng < 2) return;                                       // :332-334
+    if (ng > max_g) { if (status && lane == 0) status[b] = 1; return; }  // does not fit the LDS staging: reported, not computed
+    double* T = lds;                    // [ng] stamps
+    double* Y = T + max_g;              // [ng][3] positions
+    double* M = Y + 3 * (size_t)max_g;  // [ng][3] second derivatives (cubic segments)
+    double* W = M + 3 * (size_t)max_g;  // [ng] scratch: c' of the Thomas sweep / sort keys
+    // ---- stage + order: rank of fix k = #{j : t_j < t_k or (t_j == t_k and j < k)} (stable argsort, :339)
+    bool sorted = true;
+    for (int k = lane; k < ng; k += ALIGN_THREADS) {
+        const double tk = gps_t[g0 + k];
+        W[k] = tk;
+        if (k > 0 && !(gps_t[g0 + k - 1] < tk)) sorted = false;
+    }
+    __syncthreads();
+    sorted = (__ballot(!sorted) == 0ull);
+    if (sorted) {
+        for (int k = lane; k < ng; k += ALIGN_THREADS) {
+            T[k] = W[k];
+            Y[k * 3] = gps_p[(g0 + k) * 3]; Y[k * 3 + 1] = gps_p[(g0 + k) * 3 + 1]; Y[k * 3 + 2] = gps_p[(g0 + k) * 3 + 2];
+        }
+    } else {
+        for (int k = lane; k < ng; k += ALIGN_THREADS) {
+            const double tk = W[k];
+            int rank = 0;
+            for (int j = 0; j < ng; ++j) { const double tj = W[j]; rank += (tj < tk || (tj == tk && j < k)) ? 1 : 0; }
+            T[rank] = tk;
+            Y[rank * 3] = gps_p[(g0 + k) * 3]; Y[rank * 3 + 1] = gps_p[(g0 + k) * 3 + 1]; Y[rank * 3 + 2] = gps_p[(g0 + k) * 3 + 2];
+        }
+    }
+    __syncthreads();
+    // ---- np.unique(return_index=True): keep the first fix of every run of equal stamps (:341-346).  Compaction in place by
+    // one lane -- duplicates are rare and ng is a few hundred.
+    int nu = ng;
+    if (!sorted) {
+        if (lane == 0) {
+            int w = 0;
+            for (int k = 0; k < ng; ++k) {
+                if (w > 0 && T[k] == T[w - 1]) continue;
+                if (w != k) { T[w] = T[k]; Y[w * 3] = Y[k * 3]; Y[w * 3 + 1] = Y[k * 3 + 1]; Y[w * 3 + 2] = Y[k * 3 + 2]; }
+                ++w;
+            }
+            W[0] = (double)w;
+        }
+        __syncthreads();
+        nu = (int)W[0];
+        __syncthreads();
+    }
+    if (nu < 2) return;                                                  // :343-345
+    // ---- segments (:348-352), processed one after the other (usually 1-3 per track)
+    int seg_s = 0;
+    while (seg_s < nu) {
+        int seg_e = seg_s;                                               // wave-uniform scan for the end of the segment
+        while (seg_e + 1 < nu && !(T[seg_e + 1] - T[seg_e] > max_gap)) ++seg_e;
+        const int m = seg_e - seg_s + 1;
+        if (m >= 2) {                                                    // :360
+            bool inc = true;
+            for (int k = seg_s + lane; k < seg_e; k += ALIGN_THREADS) if (!(T[k + 1] - T[k] > 1e-9)) inc = false;     // :364
+            inc = (__ballot(!inc) == 0ull);
+            if (inc) {
+                const double* x = T + seg_s;
+                const double* y = Y + (size_t)seg_s * 3;
+                double* Ms = M + (size_t)seg_s * 3;
+                const bool cubic = m >= 4;                               // :362
+                if (cubic) {
+                    // knot second derivatives M_0..M_{m-1}:  h[i-1] M[i-1] + 2(h[i-1]+h[i]) M[i] + h[i] M[i+1] = 6 (d[i]-d[i-1]),
+                    // not-a-knot ends folded into the first / last interior row.  Lanes 0..2 = components; c' is shared.
+                    if (lane < 3) {
+                        const int c = lane, kk = m - 2;
+                        double* cp = W + seg_s;                          // c'_i of the forward sweep
+                        const double r0 = (x[1] - x[0]) / (x[2] - x[1]);
+                        const double r1 = (x[m - 1] - x[m - 2]) / (x[m - 2] - x[m - 3]);
+                        double cprev = 0.0, dprev = 0.0;
+                        for (int i = 0; i < kk; ++i) {                   // interior unknown i+1
+                            const double hl = x[i + 1] - x[i], hr = x[i + 2] - x[i + 1];
+                            double aa = hl, bb = 2.0 * (hl + hr), cc = hr;
+                            const double rhs = 6.0 * ((y[(i + 2) * 3 + c] - y[(i + 1) * 3 + c]) / hr - (y[(i + 1) * 3 + c] - y[i * 3 + c]) / hl);
+                            if (i == 0) { bb += aa * (1.0 + r0); cc -= aa * r0; aa = 0.0; }
+                            if (i == kk - 1) { bb += cc * (1.0 + r1); aa -= cc * r1; cc = 0.0; }
+                            const double den = bb - aa * cprev;
+                            const double cn = cc / den, dn = (rhs - aa * dprev) / den;
+                            cp[i] = cn;                                  // the three lanes store the same value
+                            Ms[(i + 1) * 3 + c] = dn;                    // d'_i for now
+                            cprev = cn; dprev = dn;
+                        }
+                        double xn = 0.0;
+                        for (int i = kk - 1; i >= 0; --i) {              // back substitution
+                            const double xi = Ms[(i + 1) * 3 + c] - cp[i] * xn;
+                            Ms[(i + 1) * 3 + c] = xi; xn = xi;
+                        }
+                        Ms[c] = Ms[3 + c] * (1.0 + r0) - Ms[6 + c] * r0;
+                        Ms[(m - 1) * 3 + c] = Ms[(m - 2) * 3 + c] * (1.0 + r1) - Ms[(m - 3) * 3 + c] * r1;
+                    }
+                }
+                __syncthreads();
+                const double t0 = x[0], t1 = x[m - 1];
+                for (int64_t i = lane; i < ns; i += ALIGN_THREADS) {
+                    const double t = st[i];
+                    if (!(t >= t0 - 1e-9 && t <= t1 + 1e-9)) continue;   // :372-373
+                    double v0 = NAN, v1 = NAN, v2 = NAN;
+                    if (t >= t0 && t <= t1) {
+                        if (cubic) {
+                            int lo = 0, hi = m - 1;                      // interval [x[lo], x[lo+1]] containing t
+                            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x[mid] <= t) lo = mid; else hi = mid; }
+                            const double hh = x[lo + 1] - x[lo], A = (x[lo + 1] - t) / hh, Bc = (t - x[lo]) / hh;
+                            const double ca = (A * A * A - A) * hh * hh / 6.0, cb = (Bc * Bc * Bc - Bc) * hh * hh / 6.0;
+                            v0 = A * y[lo * 3] + Bc * y[(lo + 1) * 3] + ca * Ms[lo * 3] + cb * Ms[(lo + 1) * 3];
+                            v1 = A * y[lo * 3 + 1] + Bc * y[(lo + 1) * 3 + 1] + ca * Ms[lo * 3 + 1] + cb * Ms[(lo + 1) * 3 + 1];
+                            v2 = A * y[lo * 3 + 2] + Bc * y[(lo + 1) * 3 + 2] + ca * Ms[lo * 3 + 2] + cb * Ms[(lo + 1) * 3 + 2];
+                        } else {
+                            // scipy _call_linear: hi = clip(searchsorted(x, t, 'left'), 1, m-1); lo = hi-1
+                            int hi = 0;
+                            while (hi < m && x[hi] < t) ++hi;
+                            hi = hi < 1 ? 1 : (hi > m - 1 ? m - 1 : hi);
+                            const int lo = hi - 1;
+                            const double dx = x[hi] - x[lo], dtq = t - x[lo];
+                            v0 = (y[hi * 3] - y[lo * 3]) / dx * dtq + y[lo * 3];
+                            v1 = (y[hi * 3 + 1] - y[lo * 3 + 1]) / dx * dtq + y[lo * 3 + 1];
+                            v2 = (y[hi * 3 + 2] - y[lo * 3 + 2]) / dx * dtq + y[lo * 3 + 2];
+                        }
+                    }
+                    al[i * 3] = v0; al[i * 3 + 1] = v1; al[i * 3 + 2] = v2;                       // :375
+                    va[i] = !(isnan(v0) || isnan(v1) || isnan(v2)) ? 1 : 0;                         // :377-379
+                }
+                __syncthreads();
+            }
+        }
+        seg_s = seg_e + 1;
+    }
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int gsf_time_align_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
+                             const int64_t* gps_offsets, int64_t B, int32_t max_gps_per_trajectory, double max_gps_gap_threshold,
+                             double* aligned, uint8_t* valid, int32_t* status)
+{
+    GSF_REQUIRE(ctx && slam_offsets && gps_offsets && aligned && valid, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    GSF_REQUIRE(max_gps_per_trajectory >= 2 && max_gps_per_trajectory <= 2560, "max_gps_per_trajectory must be in [2, 2560] (LDS staging)");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)max_gps_per_trajectory * 8 * sizeof(double);          // T + Y(3) + M(3) + W
+    if (lds > 64 * 1024)
+        GSF_HIP(hipFuncSetAttribute((const void*)time_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(time_align_kernel, dim3((unsigned)B), dim3(ALIGN_THREADS), lds, ctx->stream, slam_t, slam_offsets, gps_t, gps_p, gps_offsets,
+                       max_gps_gap_threshold, (int)max_gps_per_trajectory, aligned, valid, status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_time_align_batch(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
+                         const int64_t* gps_offsets, int64_t B, double max_gps_gap_threshold, double* aligned, uint8_t* valid, int32_t* status)
+{
+    GSF_REQUIRE(ctx && slam_offsets && gps_offsets && B >= 0, "bad arguments");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    const int64_t ns = slam_offsets[B], ng = gps_offsets[B];
+    GSF_REQUIRE(ns >= 0 && ng >= 0 && (ns == 0 || (slam_t && aligned && valid)) && (ng == 0 || (gps_t && gps_p)), "bad offsets / NULL arrays");
+    int64_t maxg = 2;
+    for (int64_t b = 0; b < B; ++b) { const int64_t g = gps_offsets[b + 1] - gps_offsets[b]; if (g > maxg) maxg = g; }
+    GSF_REQUIRE(maxg <= 2560, "more than 2560 GNSS fixes in one trajectory: split the track (LDS staging limit of this kernel)");
+    DevBuf d;
+    GSF_HIP(d.alloc((size_t)ns * (8 + 24 + 1) + (size_t)ng * 32 + (size_t)(B + 1) * 16 + (size_t)B * 4 + 64));
+    double* dst = (double*)d.p; double* dal = dst + ns; double* dgt = dal + 3 * ns; double* dgp = dgt + ng;
+    int64_t* dso = (int64_t*)(dgp + 3 * ng); int64_t* dgo = dso + (B + 1); int32_t* dstat = (int32_t*)(dgo + (B + 1)); uint8_t* dva = (uint8_t*)(dstat + B);
+#define H2D(dst_, src_, bytes) GSF_HIP(hipMemcpyAsync((dst_), (src_), (bytes), hipMemcpyHostToDevice, ctx->stream))
+#define D2H(dst_, src_, bytes) GSF_HIP(hipMemcpyAsync((dst_), (src_), (bytes), hipMemcpyDeviceToHost, ctx->stream))
+    if (ns) H2D(dst, slam_t, (size_t)ns * 8);
+    if (ng) { H2D(dgt, gps_t, (size_t)ng * 8); H2D(dgp, gps_p, (size_t)ng * 24); }
+    H2D(dso, slam_offsets, (size_t)(B + 1) * 8); H2D(dgo, gps_offsets, (size_t)(B + 1) * 8);
+    int rc = gsf_time_align_batch_dev(ctx, dst, dso, dgt, dgp, dgo, B, (int32_t)maxg, max_gps_gap_threshold, dal, dva, dstat);
+    if (rc) return rc;
+    if (ns) { D2H(aligned, dal, (size_t)ns * 24); D2H(valid, dva, (size_t)ns); }
+    if (status) D2H(status, dstat, (size_t)B * 4);
+    GSF_HIP(hipStreamSynchronize(ctx->stream));
+#undef H2D
+#undef D2H
+    return GSF_OK;
+}
+
+}  // extern "C"

@@ -7,8 +7,8 @@ CPU fallback: without the library / a device the first call raises GsfError.
 
 What stays host Python, as in the reference: text I/O (np.loadtxt/np.savetxt), the RNG draws of the
 Sim3 RANSAC (np.random.choice on the legacy global stream, so a seeded run reproduces the
-reference's), and -- until their device kernels land -- the time alignment
-(scipy interp1d, exactly the reference's call) and the optional sklearn GPS outlier filter.
+reference's), and -- until its device kernel lands -- the optional sklearn GPS outlier
+filter.  The time alignment (next-1) is a device kernel (gsf_time_align_batch).
 """
 import copy
 import ctypes as C
@@ -221,8 +221,27 @@ def estimate_time_offset(slam_times, gps_times, max_samples):
 
 
 def dynamic_time_alignment(slam_data, gps_data_source, time_align_config):
-    """GPS positions interpolated onto the SLAM stamps, per gap-free segment (ref :325-387).
-    Returns (aligned (N,3) with NaN where unavailable, valid_mask (N,) bool).  Host-side for now (next-1)."""
+    """GPS positions interpolated onto the SLAM stamps, per gap-free segment (ref :325-387): returns
+    (aligned (N,3) with NaN where unavailable, valid_mask (N,) bool).  One launch of the alignment kernel
+    (gsf_time_align_batch: sort/unique, gap split, not-a-knot cubic / linear, evaluation).  Tracks with more than 2560 fixes
+    exceed the kernel's LDS staging and use dynamic_time_alignment_scipy."""
+    slam_times = f64(slam_data["timestamps"]).ravel()
+    gps_times = f64(gps_data_source["timestamps"]).ravel()
+    n_slam, n_gps = len(slam_times), len(gps_times)
+    if n_slam == 0 or n_gps < 2:
+        return np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
+    gps_positions = f64(gps_data_source["positions"], (n_gps, 3))
+    if n_gps > 2560:
+        return dynamic_time_alignment_scipy(slam_data, gps_data_source, time_align_config)
+    so, go = np.array([0, n_slam], dtype=np.int64), np.array([0, n_gps], dtype=np.int64)
+    aligned, valid, st = np.empty((n_slam, 3)), np.zeros(n_slam, dtype=np.uint8), np.zeros(1, dtype=np.int32)
+    check(_lib.load().gsf_time_align_batch(_ctx().handle, hptr(slam_times), hptr(so), hptr(gps_times), hptr(gps_positions), hptr(go), 1,
+                                           float(time_align_config["max_gps_gap_threshold"]), hptr(aligned), hptr(valid), hptr(st)))
+    return aligned, valid.astype(bool)
+
+
+def dynamic_time_alignment_scipy(slam_data, gps_data_source, time_align_config):
+    """The reference's own formulation on the host (scipy interp1d), kept for very long GNSS tracks and as a cross-check."""
     from scipy.interpolate import interp1d
     slam_times, gps_times, gps_positions = slam_data["timestamps"], gps_data_source["timestamps"], gps_data_source["positions"]
     gap_thr = time_align_config["max_gps_gap_threshold"]
@@ -232,7 +251,7 @@ def dynamic_time_alignment(slam_data, gps_data_source, time_align_config):
         return aligned, valid
     adj = gps_times + estimate_time_offset(slam_times, gps_times, time_align_config["max_samples_for_corr"])
     try:
-        order = np.argsort(adj)
+        order = np.argsort(adj, kind="stable")
         ts, ps = adj[order], gps_positions[order]
         uniq, first = np.unique(ts, return_index=True)
         if len(uniq) < 2:

@@ -432,3 +432,68 @@ def test_rccl_allgather_wrapper_single_rank(B):
             assert torch.equal(send, recv), (mode, chunk)
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+# ------------------------------------------------------------------ next-1: time alignment on the device
+def test_time_alignment_kernel_vs_goldens_and_oracle(E, orc, golden):
+    g = golden("align_cases.npz")
+    for name in g["names"]:
+        slam = {"timestamps": g[f"{name}_st"]}
+        gps = {"timestamps": g[f"{name}_gt"], "positions": g[f"{name}_gp"]}
+        al, va = E.dynamic_time_alignment(slam, gps, {"max_samples_for_corr": 500, "max_gps_gap_threshold": float(g[f"{name}_gap"])})
+        np.testing.assert_array_equal(va, g[f"{name}_va"], err_msg=str(name))
+        np.testing.assert_array_equal(np.isnan(al), np.isnan(g[f"{name}_al"]), err_msg=str(name))
+        # vs the reference (scipy's B-spline loses ~1e-7 m on irregular knots, see tests/test_oracle_golden.py) ...
+        tol = 5e-7 if str(name) in ("random_knots", "two_gaps", "unsorted_dups", "exact_knots", "small_gap_thr") else 1e-8
+        np.testing.assert_allclose(al[va], g[f"{name}_al"][va], atol=tol, rtol=0, err_msg=str(name))
+        # ... and vs the oracle's exact-to-2-ulp spline
+        alo, vao = orc.dynamic_time_alignment(g[f"{name}_st"], g[f"{name}_gt"], g[f"{name}_gp"], 500, float(g[f"{name}_gap"]))
+        np.testing.assert_array_equal(va, vao)
+        np.testing.assert_allclose(al[va], alo[va], atol=2e-8, rtol=0, err_msg=str(name))
+
+
+def test_time_alignment_kat4_and_c1(E, golden):
+    k = golden("kat_bundled.npz")
+    al, va = E.dynamic_time_alignment({"timestamps": k["ts"]}, {"timestamps": k["kat4_gps_t"], "positions": k["kat4_gps_p"]}, E.CONFIG["time_alignment"])
+    np.testing.assert_array_equal(va, k["kat4_valid"])
+    np.testing.assert_allclose(al[va], k["kat4_aligned"][va], atol=1e-9, rtol=0)
+    for tag in ("kitti04gps", "combined"):
+        g = golden(f"c1_{tag}.npz")
+        al, va = E.dynamic_time_alignment({"timestamps": k["ts"]}, {"timestamps": g["gps_t"], "positions": g["gps_p"]}, E.CONFIG["time_alignment"])
+        np.testing.assert_array_equal(va, g["valid"])
+        np.testing.assert_allclose(al[va], g["aligned"][va], atol=1e-8, rtol=0)
+
+
+def test_time_alignment_batch_ragged(B, orc):
+    """Batched device entry: ragged SLAM / GNSS tracks, unsorted + duplicated stamps, gaps, short segments."""
+    import ctypes as C
+    import torch
+    from gps_optimize_slam_amd import _lib
+    rng = np.random.default_rng(17)
+    st_l, gt_l, gp_l = [], [], []
+    for b in range(40):
+        ns, ng = int(rng.integers(1, 400)), int(rng.integers(0, 350))
+        st = np.sort(rng.uniform(0, 40, ns))
+        gt = np.sort(rng.uniform(0, 40, ng))
+        if b % 3 == 0 and ng > 30:
+            gt = gt[(gt < 10) | (gt > 17)]                     # a gap > 5 s
+        gp = np.c_[np.sin(gt) * 50 + 4.5e5, gt * 13 + 5.4e6, np.cos(gt / 3) + 100]
+        if b % 4 == 1 and len(gt) > 10:                        # shuffle + duplicate a few stamps (identical positions)
+            perm = rng.permutation(len(gt)); gt, gp = np.r_[gt[perm], gt[:5]], np.r_[gp[perm], gp[:5]]
+        st_l.append(st); gt_l.append(gt); gp_l.append(gp.reshape(-1, 3))
+    so = np.cumsum([0] + [len(x) for x in st_l]).astype(np.int64); go = np.cumsum([0] + [len(x) for x in gt_l]).astype(np.int64)
+    d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dt).cuda()
+    dst, dgt, dgp, dso, dgo = d(np.concatenate(st_l)), d(np.concatenate(gt_l)), d(np.concatenate(gp_l)), d(so, torch.int64), d(go, torch.int64)
+    al = torch.empty((int(so[-1]), 3), dtype=torch.float64, device="cuda"); va = torch.empty(int(so[-1]), dtype=torch.uint8, device="cuda")
+    stt = torch.empty(40, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.load().gsf_time_align_batch_dev(B.context().handle, p(dst), p(dso), p(dgt), p(dgp), p(dgo), 40, 512, 5.0, p(al), p(va), p(stt)))
+    torch.cuda.synchronize()
+    al, va = al.cpu().numpy(), va.cpu().numpy().astype(bool)
+    assert (stt.cpu().numpy() == 0).all()
+    for b in range(40):
+        alo, vao = orc.dynamic_time_alignment(st_l[b], gt_l[b], gp_l[b], 500, 5.0)
+        sl = slice(so[b], so[b + 1])
+        np.testing.assert_array_equal(va[sl], vao, err_msg=str(b))
+        np.testing.assert_allclose(al[sl][vao], alo[vao], atol=5e-8, rtol=0, err_msg=str(b))
+        assert np.isnan(al[sl][~vao]).all()
