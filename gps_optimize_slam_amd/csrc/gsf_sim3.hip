@@ -5,24 +5,17 @@
 //
 // K2: the fit is a reduction (centroids, then the 3x3 cross-covariance of the CENTRED points --
 // raw moments would cancel catastrophically at UTM magnitudes ~5e6 m) followed by a 3x3 SVD.
-// One wavefront reduces one point set with DPP/shuffle butterflies (no LDS, no atomics); the SVD +
+// One wavefront reduces one point set with DPP-routed scans (no LDS, no atomics); the SVD +
 // closed form then runs LANE-PARALLEL: a 64-thread block owns 64 point sets, wave-reduces them one
 // after another and parks the 19 moments of set k in lane k's registers, so the ~500-instruction
 // Jacobi SVD is paid once per 64 sets instead of once per set.
 // K2b: one 256-thread block per point set; one hypothesis per thread (4-point fit entirely in
 // registers), all hypotheses score the same points so the reads are wave-broadcasts out of L1/L2.
-#include "gsf_internal.hpp"
+#include "gsf_wave_common.hpp"      // DPP-routed wave_sum()
 
 using namespace gsf;
 
 namespace {
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 struct Moments { double n, sc[3], dc[3], H[9], ssq; };
 

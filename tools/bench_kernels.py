@@ -1,0 +1,68 @@
+"""Times the non-EKF kernels on BASELINE-shaped workloads (GPU box): K1 UTM fwd/inv, K2 Umeyama windows (C4), K2b RANSAC,
+K3 apply-Sim3, time alignment.  Prints one JSON object per kernel with algorithmic GB/s (SURVEY 8d byte counts)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+import torch
+from gps_optimize_slam_amd import batch as B, _lib
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+out = {}
+dev = "cuda"
+g = torch.Generator(device=dev); g.manual_seed(1)
+# ---- K1: 1e8 points in 1e5 trajectories of 1000
+nb, n = 100_000, 1000
+lat = 49.03 + 0.02 * (torch.rand(nb * n, dtype=torch.float64, device=dev, generator=g) - 0.5)
+lon = 8.39 + 0.02 * (torch.rand(nb * n, dtype=torch.float64, device=dev, generator=g) - 0.5)
+offs = torch.arange(0, nb * n + 1, n, dtype=torch.int64, device=dev)
+e, nn, zone, south = B.utm_forward_batch(lat, lon, offs)
+ms = timed(lambda: B.utm_forward_batch(lat, lon, offs, zone, south))
+out["K1_utm_forward_1e8pts"] = {"ms": ms, "Gpts_s": nb * n / ms / 1e6, "alg_GBps": nb * n * 32 / ms / 1e6}
+ms = timed(lambda: B.utm_inverse_batch(e, nn, offs, zone, south))
+out["K1_utm_inverse_1e8pts"] = {"ms": ms, "Gpts_s": nb * n / ms / 1e6, "alg_GBps": nb * n * 32 / ms / 1e6}
+ms = timed(lambda: B.utm_forward_batch(lat, lon, offs))
+out["K1_zone_pick_plus_forward"] = {"ms": ms}
+del lat, lon, e, nn
+# ---- K2: C4 = 1M windows x 50 pairs
+nw, W = 1_000_000, 50
+src = torch.cumsum(torch.randn(nw, W, 3, dtype=torch.float64, device=dev, generator=g) * torch.tensor([0.05, 0.03, 1.4], dtype=torch.float64, device=dev), dim=1)
+dst = 1.05 * src + torch.tensor([4.5e5, 5.4e6, 100.0], dtype=torch.float64, device=dev) + 0.45 * torch.randn(nw, W, 3, dtype=torch.float64, device=dev, generator=g)
+ms = timed(lambda: B.sim3_umeyama_batch(src, dst))
+out["K2_umeyama_C4_1Mx50"] = {"ms": ms, "Mwindows_s": nw / ms / 1e3, "alg_GBps": nw * (48 * W + 104) / ms / 1e6}
+# ---- K3: apply sim3 to 1e8 poses (1e5 x 1000)
+del src, dst
+pos = torch.randn(nb * n, 3, dtype=torch.float64, device=dev, generator=g); quat = torch.randn(nb * n, 4, dtype=torch.float64, device=dev, generator=g)
+R = torch.eye(3, dtype=torch.float64, device=dev).reshape(1, 9).repeat(nb, 1).contiguous(); t = torch.zeros(nb, 3, dtype=torch.float64, device=dev); s = torch.ones(nb, dtype=torch.float64, device=dev)
+ms = timed(lambda: B.apply_sim3_batch(pos, quat, offs, R, t, s))
+out["K3_apply_sim3_1e8poses"] = {"ms": ms, "Gposes_s": nb * n / ms / 1e6, "alg_GBps": nb * n * 112 / ms / 1e6}
+del pos, quat
+# ---- K2b: RANSAC, 1000 trajectories x 271 points x 1000 trials (C2-shaped)
+nt, npts, trials = 1000, 271, 1000
+bt = B.TrajectoryBatch.synthetic(nt, npts, layout=B.LAYOUT_TRAJ_MAJOR, seed=3)
+srcp = bt.pos.reshape(nt * npts, 3).contiguous(); dstp = torch.nan_to_num(bt.gps.reshape(nt * npts, 3), nan=0.0).contiguous()
+offr = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device=dev)
+idx = torch.stack([torch.stack([torch.randperm(npts, device=dev)[:4] for _ in range(trials)]) for _ in range(8)]).to(torch.int32)
+idx = idx.repeat(nt // 8, 1, 1).contiguous()
+ms = timed(lambda: B.sim3_ransac_batch(srcp, dstp, offr, idx, 4.0, 4), reps=3)
+out["K2b_ransac_1000traj_271pts_1000trials"] = {"ms": ms, "traj_per_s": nt / ms * 1e3, "hypothesis_scores_per_s": nt * trials * npts / ms * 1e3}
+# ---- time alignment: 1000 trajectories, 271 SLAM stamps, 279 fixes
+st = (torch.arange(npts, dtype=torch.float64, device=dev) * 0.104).repeat(nt)
+gtn = 279
+gt = (torch.arange(gtn, dtype=torch.float64, device=dev) * 0.1047 + 0.001).repeat(nt)
+gp = torch.randn(nt * gtn, 3, dtype=torch.float64, device=dev, generator=g).cumsum(0)
+so = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device=dev); go = torch.arange(0, nt * gtn + 1, gtn, dtype=torch.int64, device=dev)
+al = torch.empty(nt * npts, 3, dtype=torch.float64, device=dev); va = torch.empty(nt * npts, dtype=torch.uint8, device=dev)
+p = lambda x: C.c_void_p(x.data_ptr())
+L, h = _lib.load(), B.context().handle
+ms = timed(lambda: _lib.check(L.gsf_time_align_batch_dev(h, p(st), p(so), p(gt), p(gp), p(go), nt, 512, 5.0, p(al), p(va), None)))
+out["align_1000traj_271x279"] = {"ms": ms, "Mposes_s": nt * npts / ms / 1e3}
+print(json.dumps(out, indent=1))
