@@ -1,7 +1,8 @@
 // gsf_align.hip -- GNSS positions interpolated onto the SLAM stamps: dynamic_time_alignment (EKFGPSSLAM.py:325-387), the
 // step right before both the Sim3 fit and the EKF (SURVEY 8f "next-1").
 //
-// One 64-lane workgroup per trajectory, the GNSS track staged in LDS (t, y[3], second derivatives M[3]: 56 B per fix):
+// One 64-lane workgroup per trajectory, the GNSS track staged in LDS (t, y[3], second derivatives M[3], c': 64 B per fix;
+// tracks of more than 2560 fixes are staged in a global scratch slab instead):
 //   1. sort by stamp if needed (rank sort, stable by input order) and keep the first of equal stamps (np.unique, :339-346);
 //   2. split at gaps > max_gps_gap_threshold (:348-352); a segment needs >= 2 fixes and stamps increasing by > 1e-9 (:364);
 //   3. >= 4 fixes: not-a-knot cubic spline (scipy interp1d(kind='cubic'), :362/:368) -- the tridiagonal system for the knot
@@ -20,10 +21,12 @@ constexpr int ALIGN_THREADS = 64;
 __global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double* __restrict__ slam_t, const int64_t* __restrict__ slam_off,
                                                                     const double* __restrict__ gps_t, const double* __restrict__ gps_p,
                                                                     const int64_t* __restrict__ gps_off, double max_gap, int max_g,
-                                                                    double* __restrict__ aligned, uint8_t* __restrict__ valid,
-                                                                    int32_t* __restrict__ status)
+                                                                    double* __restrict__ gscratch, double* __restrict__ aligned,
+                                                                    uint8_t* __restrict__ valid, int32_t* __restrict__ status)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    // staging area of this trajectory: LDS when the track fits (<= 2560 fixes), else a slab of global scratch (8 doubles per fix)
+    double* lds = gscratch ? gscratch + (size_t)blockIdx.x * 8 * (size_t)max_g : lds_;
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t s0 = slam_off[b], ns = slam_off[b + 1] - s0;
@@ -180,14 +183,20 @@ int gsf_time_align_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* 
 {
     GSF_REQUIRE(ctx && slam_offsets && gps_offsets && aligned && valid, "NULL argument");
     GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
-    GSF_REQUIRE(max_gps_per_trajectory >= 2 && max_gps_per_trajectory <= 2560, "max_gps_per_trajectory must be in [2, 2560] (LDS staging)");
+    GSF_REQUIRE(max_gps_per_trajectory >= 2 && max_gps_per_trajectory <= (1 << 24), "max_gps_per_trajectory out of range");
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
-    const size_t lds = (size_t)max_gps_per_trajectory * 8 * sizeof(double);          // T + Y(3) + M(3) + W
-    if (lds > 64 * 1024)
+    size_t lds = (size_t)max_gps_per_trajectory * 8 * sizeof(double);                // T + Y(3) + M(3) + W
+    double* gscratch = nullptr;
+    if (max_gps_per_trajectory > 2560) {                                             // does not fit 160 KB of LDS: stage in HBM scratch
+        int rc = ensure_scratch(ctx, lds * (size_t)B);
+        if (rc) return rc;
+        gscratch = (double*)ctx->scratch; lds = 0;
+    } else if (lds > 64 * 1024) {
         GSF_HIP(hipFuncSetAttribute((const void*)time_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     hipLaunchKernelGGL(time_align_kernel, dim3((unsigned)B), dim3(ALIGN_THREADS), lds, ctx->stream, slam_t, slam_offsets, gps_t, gps_p, gps_offsets,
-                       max_gps_gap_threshold, (int)max_gps_per_trajectory, aligned, valid, status);
+                       max_gps_gap_threshold, (int)max_gps_per_trajectory, gscratch, aligned, valid, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -202,7 +211,6 @@ int gsf_time_align_batch(gsf_ctx* ctx, const double* slam_t, const int64_t* slam
     GSF_REQUIRE(ns >= 0 && ng >= 0 && (ns == 0 || (slam_t && aligned && valid)) && (ng == 0 || (gps_t && gps_p)), "bad offsets / NULL arrays");
     int64_t maxg = 2;
     for (int64_t b = 0; b < B; ++b) { const int64_t g = gps_offsets[b + 1] - gps_offsets[b]; if (g > maxg) maxg = g; }
-    GSF_REQUIRE(maxg <= 2560, "more than 2560 GNSS fixes in one trajectory: split the track (LDS staging limit of this kernel)");
     DevBuf d;
     GSF_HIP(d.alloc((size_t)ns * (8 + 24 + 1) + (size_t)ng * 32 + (size_t)(B + 1) * 16 + (size_t)B * 4 + 64));
     double* dst = (double*)d.p; double* dal = dst + ns; double* dgt = dal + 3 * ns; double* dgp = dgt + ng;

@@ -223,62 +223,18 @@ def estimate_time_offset(slam_times, gps_times, max_samples):
 def dynamic_time_alignment(slam_data, gps_data_source, time_align_config):
     """GPS positions interpolated onto the SLAM stamps, per gap-free segment (ref :325-387): returns
     (aligned (N,3) with NaN where unavailable, valid_mask (N,) bool).  One launch of the alignment kernel
-    (gsf_time_align_batch: sort/unique, gap split, not-a-knot cubic / linear, evaluation).  Tracks with more than 2560 fixes
-    exceed the kernel's LDS staging and use dynamic_time_alignment_scipy."""
+    (gsf_time_align_batch: sort/unique, gap split, not-a-knot cubic / linear, evaluation)."""
     slam_times = f64(slam_data["timestamps"]).ravel()
     gps_times = f64(gps_data_source["timestamps"]).ravel()
     n_slam, n_gps = len(slam_times), len(gps_times)
     if n_slam == 0 or n_gps < 2:
         return np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
     gps_positions = f64(gps_data_source["positions"], (n_gps, 3))
-    if n_gps > 2560:
-        return dynamic_time_alignment_scipy(slam_data, gps_data_source, time_align_config)
     so, go = np.array([0, n_slam], dtype=np.int64), np.array([0, n_gps], dtype=np.int64)
     aligned, valid, st = np.empty((n_slam, 3)), np.zeros(n_slam, dtype=np.uint8), np.zeros(1, dtype=np.int32)
     check(_lib.load().gsf_time_align_batch(_ctx().handle, hptr(slam_times), hptr(so), hptr(gps_times), hptr(gps_positions), hptr(go), 1,
                                            float(time_align_config["max_gps_gap_threshold"]), hptr(aligned), hptr(valid), hptr(st)))
     return aligned, valid.astype(bool)
-
-
-def dynamic_time_alignment_scipy(slam_data, gps_data_source, time_align_config):
-    """The reference's own formulation on the host (scipy interp1d), kept for very long GNSS tracks and as a cross-check."""
-    from scipy.interpolate import interp1d
-    slam_times, gps_times, gps_positions = slam_data["timestamps"], gps_data_source["timestamps"], gps_data_source["positions"]
-    gap_thr = time_align_config["max_gps_gap_threshold"]
-    n_slam, n_gps = len(slam_times), len(gps_times)
-    aligned, valid = np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
-    if n_slam == 0 or n_gps < 2:
-        return aligned, valid
-    adj = gps_times + estimate_time_offset(slam_times, gps_times, time_align_config["max_samples_for_corr"])
-    try:
-        order = np.argsort(adj, kind="stable")
-        ts, ps = adj[order], gps_positions[order]
-        uniq, first = np.unique(ts, return_index=True)
-        if len(uniq) < 2:
-            return aligned, valid
-        if len(uniq) < n_gps:
-            ts, ps = uniq, ps[first]
-        gaps = np.where(np.diff(ts) > gap_thr)[0]
-        starts, ends = [0] + (gaps + 1).tolist(), gaps.tolist() + [len(ts) - 1]
-        for s, e in zip(starts, ends):
-            seg_len = e - s + 1
-            if seg_len < 2:
-                continue
-            st, sp = ts[s:e + 1], ps[s:e + 1]
-            if not np.all(np.diff(st) > 1e-9):
-                continue
-            try:
-                fn = interp1d(st, sp, axis=0, kind="cubic" if seg_len >= 4 else "linear", bounds_error=False, fill_value=np.nan)
-            except ValueError:
-                continue
-            idx = np.where((slam_times >= st[0] - 1e-9) & (slam_times <= st[-1] + 1e-9))[0]
-            if len(idx) > 0:
-                vals = fn(slam_times[idx])
-                aligned[idx] = vals
-                valid[idx[~np.isnan(vals).any(axis=1)]] = True
-        return aligned, valid
-    except ValueError:
-        return np.full((n_slam, 3), np.nan), np.zeros(n_slam, dtype=bool)
 
 
 # ---------------------------------------------------------------------------- Sim3 (EKFGPSSLAM.py:389-467)

@@ -171,8 +171,9 @@ GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const doub
 /* B trajectories: SLAM stamps slam_t[slam_offsets[b]..), GNSS fixes gps_t / gps_p[.][3] at gps_offsets (any order, duplicates
    allowed: stable sort + first-of-equal-stamps).  Per gap-free segment (gap > max_gps_gap_threshold splits): not-a-knot cubic
    spline (>= 4 fixes) or linear (2-3 fixes) evaluated at the SLAM stamps inside the segment; aligned[total_slam][3] gets NaN
-   elsewhere, valid[total_slam] = 1 where all three components are finite.  status[b] (may be NULL) = 1 if trajectory b has more
-   GNSS fixes than max_gps_per_trajectory (LDS staging; <= 2560) and was left unaligned. */
+   elsewhere, valid[total_slam] = 1 where all three components are finite.  max_gps_per_trajectory sizes the per-trajectory staging
+   (LDS up to 2560 fixes, a global scratch slab beyond); status[b] (may be NULL) = 1 if trajectory b has more fixes than that and
+   was left unaligned. */
 GSF_API int gsf_time_align_batch_dev(gsf_ctx *ctx, const double *slam_t, const int64_t *slam_offsets, const double *gps_t,
                                      const double *gps_p, const int64_t *gps_offsets, int64_t B, int32_t max_gps_per_trajectory,
                                      double max_gps_gap_threshold, double *aligned, uint8_t *valid, int32_t *status);

@@ -497,3 +497,44 @@ def test_time_alignment_batch_ragged(B, orc):
         np.testing.assert_array_equal(va[sl], vao, err_msg=str(b))
         np.testing.assert_allclose(al[sl][vao], alo[vao], atol=5e-8, rtol=0, err_msg=str(b))
         assert np.isnan(al[sl][~vao]).all()
+
+
+def test_time_alignment_long_track_global_staging(E, orc):
+    """More than 2560 fixes: the kernel stages the track in global scratch instead of LDS."""
+    rng = np.random.default_rng(23)
+    gt = np.sort(rng.uniform(0, 400, 5000)); gt = gt[np.r_[True, np.diff(gt) > 1e-6]]
+    gp = np.c_[np.sin(gt / 7) * 500 + 4.5e5, gt * 13 + 5.4e6, np.cos(gt / 30) * 10 + 100]
+    st = np.arange(3800) * 0.104
+    al, va = E.dynamic_time_alignment({"timestamps": st}, {"timestamps": gt, "positions": gp}, E.CONFIG["time_alignment"])
+    alo, vao = orc.dynamic_time_alignment(st, gt, gp, 500, 5.0)
+    np.testing.assert_array_equal(va, vao)
+    np.testing.assert_allclose(al[va], alo[va], atol=5e-8, rtol=0)
+
+
+def test_c3_full_size_properties(B):
+    """BASELINE config C3 at FULL size (100 000 x 1 000 poses, 14.5 GB): size-independent properties of the fused batch."""
+    import torch
+    nb, N = 100_000, 1000
+    batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=20250523)
+    out, R, t, s = B.fuse_pipeline_batch(batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.pos).all() and torch.isfinite(out.quat).all() and torch.isfinite(s).all()
+    assert ((out.quat.pow(2).sum(dim=2) - 1).abs().max().item()) < 1e-12                 # unit quaternions
+    assert (s - 1.0).abs().max().item() < 0.12                                            # planted scales are U(0.9, 1.1)
+    st = out.status.cpu().numpy()
+    assert ((st >> 8) == 0).all()                                                          # every fit succeeded
+    frac_out, frac_rts, frac_end = ((st & 1) > 0).mean(), ((st & 2) > 0).mean(), ((st & 8) > 0).mean()
+    assert 0.12 < frac_out < 0.16 and 0.09 < frac_rts < 0.13 and 0.015 < frac_end < 0.025
+    # fused track stays within a few GNSS sigmas of the valid fixes (sigma = 0.45 m)
+    err = (out.pos - batch.gps).norm(dim=2)
+    ok = batch.valid.bool() & torch.isfinite(err)
+    assert err[ok].mean().item() < 1.0
+    # shard invariance at full size: a checksum of a 1 000-trajectory slice regenerated as its own batch matches bit for bit
+    sub = B.TrajectoryBatch.synthetic(1000, N, layout=0, seed=20250523, traj0=54_000)
+    outs, _, _, _ = B.fuse_pipeline_batch(sub)
+    torch.cuda.synchronize()
+    assert torch.equal(outs.pos, out.pos[54_000:55_000]) and torch.equal(outs.quat, out.quat[54_000:55_000])
+    # idempotence
+    out2, _, _, _ = B.fuse_pipeline_batch(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(out.pos, out2.pos)
