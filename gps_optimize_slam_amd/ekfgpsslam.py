@@ -433,6 +433,22 @@ class ExtendedKalmanFilter:
         return self.state, self.cov, ps, pc.reshape(7, 7)
 
 
+# ---------------------------------------------------------------------------- error evaluation (EKFGPSSLAM.py:1013-1033)
+def evaluate_trajectory_errors(slam_timestamps, traj_positions, aligned_gps, valid_mask, skip_seconds=5.0):
+    """The reference's error metric (step 6 of main_process_gui, ref :1013-1033): for every SLAM index with a
+    valid aligned GNSS fix after the first `skip_seconds`, the minimum distance to ANY such candidate fix; returns
+    {'count','mean','median','rmse','errors'(N, NaN where not evaluated)}.  One kernel launch (gsf_eval_errors_batch)."""
+    ts = f64(slam_timestamps).ravel()
+    n = ts.size
+    tp, gp = f64(traj_positions, (n, 3)), f64(aligned_gps, (n, 3))
+    va = np.ascontiguousarray(valid_mask, dtype=np.uint8).reshape(n)
+    stats, err = np.empty((1, 4)), np.empty(n)
+    if n == 0:
+        return {"count": 0, "mean": np.nan, "median": np.nan, "rmse": np.nan, "errors": err}
+    check(_lib.load().gsf_eval_errors_batch(_ctx().handle, hptr(ts), hptr(tp), hptr(gp), hptr(va), 1, n, float(skip_seconds), hptr(stats), hptr(err)))
+    return {"count": int(stats[0, 0]), "mean": float(stats[0, 1]), "median": float(stats[0, 2]), "rmse": float(stats[0, 3]), "errors": err}
+
+
 # ---------------------------------------------------------------------------- headless driver (EKFGPSSLAM.py:940-1104, no GUI)
 def pick_sim3_indices(slam_data, valid_mask, config=None):
     """Which time-synchronised points feed the global Sim3 (first gap-free segment, <= max_initial_duration) -- ref :973-998."""
@@ -475,5 +491,7 @@ def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):
         if out_wgs == out_path_utm:
             out_wgs = out_path_utm.replace(".txt", "_wgs84.txt") if ".txt" in out_path_utm else out_path_utm + "_wgs84.txt"
         save_tum_wgs84(out_wgs, slam["timestamps"], wgs, quat)
+    err_sim3 = evaluate_trajectory_errors(slam["timestamps"], sim3_pos, aligned, valid)          # step 6 (vs the primary GPS)
+    err_ekf = evaluate_trajectory_errors(slam["timestamps"], pos, aligned, valid)
     return {"slam": slam, "gps": gps, "aligned": aligned, "valid": valid, "sim3_idx": idx, "R": R, "t": t, "s": s,
-            "sim3_pos": sim3_pos, "sim3_quat": sim3_quat, "pos": pos, "quat": quat}
+            "sim3_pos": sim3_pos, "sim3_quat": sim3_quat, "pos": pos, "quat": quat, "err_sim3": err_sim3, "err_ekf": err_ekf}

@@ -181,6 +181,15 @@ GSF_API int gsf_time_align_batch(gsf_ctx *ctx, const double *slam_t, const int64
                                  const int64_t *gps_offsets, int64_t B, double max_gps_gap_threshold, double *aligned, uint8_t *valid,
                                  int32_t *status);
 
+/* ---- error evaluation (main_process_gui step 6, EKFGPSSLAM.py:1013-1033) -------------------- */
+/* B trajectories x N poses, trajectory-major.  For every index with valid finite aligned GNSS and ts > ts[0] + skip_seconds:
+   error = min over all such candidate fixes of |traj_pos[i] - gps[j]| (cdist + min, :1030-1031).
+   stats[B][4] = {count, mean, median, rmse} (:1033); errors[B][N] = per-pose error, NaN where not evaluated. */
+GSF_API int gsf_eval_errors_batch_dev(gsf_ctx *ctx, const double *ts, const double *traj_pos, const double *aligned_gps,
+                                      const uint8_t *valid, int64_t B, int64_t N, double skip_seconds, double *stats, double *errors);
+GSF_API int gsf_eval_errors_batch(gsf_ctx *ctx, const double *ts, const double *traj_pos, const double *aligned_gps, const uint8_t *valid,
+                                  int64_t B, int64_t N, double skip_seconds, double *stats, double *errors);
+
 /* ---- helper functions of the reference's EKF surface (API completeness; host pointers, synchronous) ------------ */
 /* calculate_relative_pose (EKFGPSSLAM.py:77-92) for n pose pairs; bad[i]=1 where the zero-motion branch (:84-86) was taken */
 GSF_API int gsf_relative_pose_batch(gsf_ctx *ctx, const double *p1, const double *q1, const double *p2, const double *q2, int64_t n,

@@ -538,3 +538,31 @@ def test_c3_full_size_properties(B):
     out2, _, _, _ = B.fuse_pipeline_batch(batch)
     torch.cuda.synchronize()
     assert torch.equal(out.pos, out2.pos)
+
+
+# ------------------------------------------------------------------ next-4: the reference's error metric on the device
+@pytest.mark.parametrize("tag", ["kitti04gps", "combined"])
+def test_error_metric_kernel_vs_reference(E, golden, tag):
+    g, k = golden(f"c1_{tag}.npz"), golden("kat_bundled.npz")
+    for traj, ref in ((g["sim3_pos"], g["err_sim3"]), (g["ekf_pos"], g["err_ekf"])):
+        r = E.evaluate_trajectory_errors(k["ts"], traj, g["aligned"], g["valid"])
+        post = g["valid"] & (k["ts"] > k["ts"][0] + 5.0)
+        assert r["count"] == int(post.sum())
+        np.testing.assert_allclose([r["mean"], r["median"], r["rmse"]], ref, atol=1e-9, rtol=0)
+        assert np.isnan(r["errors"][~post]).all() and np.isfinite(r["errors"][post]).all()
+
+
+def test_run_fusion_headless_driver(E, golden, tmp_path):
+    """Steps 1-7 of main_process_gui without the GUI, file in / file out, on a copy of the bundled-shaped data."""
+    g, k = golden("c1_combined.npz"), golden("kat_bundled.npz")
+    slam_f, gps_f = tmp_path / "traj.txt", tmp_path / "gps.txt"
+    np.savetxt(slam_f, np.column_stack((k["ts"], k["pos"], k["quat"])))
+    np.savetxt(gps_f, np.column_stack((g["gps_t_raw"], g["lat"], g["lon"], g["alt"], np.full(len(g["lat"]), 4), np.full(len(g["lat"]), 5))), fmt="%.18e")
+    np.random.seed(0)
+    out = E.run_fusion(str(slam_f), str(gps_f), out_path_utm=str(tmp_path / "traj_corrected_utm.txt"))
+    assert out["gps"]["utm_zone"] == "32N"
+    np.testing.assert_allclose(out["pos"], g["ekf_pos"], atol=POS_TOL, rtol=0)       # same seed, same RNG order as the reference run
+    assert abs(out["err_ekf"]["rmse"] - g["err_ekf"][2]) < 1e-8
+    assert (tmp_path / "traj_corrected_utm.txt").exists() and (tmp_path / "traj_corrected_wgs84.txt").exists()
+    w = np.loadtxt(tmp_path / "traj_corrected_wgs84.txt", skiprows=1)
+    assert abs(w[0, 1] - 8.395) < 1e-2 and abs(w[0, 2] - 49.0336) < 1e-2             # lon, lat of KITTI-04
