@@ -80,6 +80,8 @@ SIGNATURES = {
     "gsf_ekf_fuse_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_ekf_fuse_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_ekf_fuse_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp]),
+    "gsf_fuse_pipeline_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_time_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
     "gsf_time_align_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "gsf_eval_errors_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _vp]),

@@ -194,3 +194,28 @@ def utm_inverse_batch(e, n, offsets, zone, south):
     lat, lon = torch.empty_like(e), torch.empty_like(e)
     check(_lib.load().gsf_utm_inverse_batch_dev(context().handle, _p(e), _p(n), _p(offsets), _p(zone), _p(south), B, _p(lat), _p(lon)))
     return lat, lon
+
+
+def fuse_pipeline_ragged(ts, pos, quat, gps, valid, offsets, config=None):
+    """Fused Umeyama -> Sim3(pose 0) -> EKF+RTS for trajectories of DIFFERENT lengths: flat device tensors ts (T,), pos (T,3),
+    quat (T,4), gps (T,3), valid (T,) uint8 and int64 offsets (B+1,).  Returns pos_out, quat_out, status, R, t, s."""
+    cfg = EkfConfig.from_config(config or CONFIG)
+    B = offsets.numel() - 1
+    f = dict(dtype=torch.float64, device=ts.device)
+    po, qo = torch.empty_like(pos), torch.empty_like(quat)
+    R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
+    st = torch.empty((B,), dtype=torch.int32, device=ts.device)
+    check(_lib.load().gsf_fuse_pipeline_ragged_dev(context().handle, _p(ts), _p(pos), _p(quat), _p(gps), _p(valid), _p(offsets), C.byref(cfg), B,
+                                                   _p(R), _p(t), _p(s), _p(po), _p(qo), _p(st)))
+    return po, qo, st, R, t, s
+
+
+def ekf_fuse_ragged(ts, pos, quat, gps, valid, offsets, init_pos, init_quat, config=None):
+    """K4 for trajectories of different lengths (flat tensors + offsets, see fuse_pipeline_ragged)."""
+    cfg = EkfConfig.from_config(config or CONFIG)
+    B = offsets.numel() - 1
+    po, qo = torch.empty_like(pos), torch.empty_like(quat)
+    st = torch.empty((B,), dtype=torch.int32, device=ts.device)
+    check(_lib.load().gsf_ekf_fuse_ragged_dev(context().handle, _p(ts), _p(pos), _p(quat), _p(gps), _p(valid), _p(offsets), _p(init_pos),
+                                              _p(init_quat), C.byref(cfg), B, _p(po), _p(qo), _p(st)))
+    return po, qo, st

@@ -266,3 +266,29 @@ extern "C" int gsf_fuse_pipeline_batch_dev(gsf_ctx* ctx, int32_t layout, const d
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
+
+// ---- ragged batches: B trajectories of different lengths, rows offsets[b]..offsets[b+1] of flat [total][C] arrays -------------
+extern "C" int gsf_ekf_fuse_ragged_dev(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
+                                       const uint8_t* valid, const int64_t* offsets, const double* init_pos, const double* init_quat,
+                                       const gsf_ekf_config* cfg, int64_t B, double* pos_out, double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(ctx && cfg && offsets, "ctx/cfg/offsets is NULL");
+    GSF_REQUIRE(B >= 0, "negative B");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(ts && pos && quat && gps && valid && init_pos && init_quat && pos_out && quat_out, "NULL array");
+    GSF_HIP(hipSetDevice(ctx->device));
+    return launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, 0, nullptr, nullptr, nullptr, pos_out, quat_out,
+                           status, offsets);
+}
+
+extern "C" int gsf_fuse_pipeline_ragged_dev(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
+                                            const uint8_t* valid, const int64_t* offsets, const gsf_ekf_config* cfg, int64_t B, double* R,
+                                            double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(ctx && cfg && offsets, "ctx/cfg/offsets is NULL");
+    GSF_REQUIRE(B >= 0, "negative B");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(ts && pos && quat && gps && valid && R && t && s && pos_out && quat_out, "NULL array");
+    GSF_HIP(hipSetDevice(ctx->device));
+    return launch_ekf_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, 0, R, t, s, pos_out, quat_out, status, offsets);
+}

@@ -355,7 +355,7 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
                      int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
 {
     GSF_REQUIRE(B <= 0x7fffffff && N >= 1 && N <= 64 * MAXW, "launch_ekf_block: needs N <= 1024");
-    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N };
+    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, nullptr };
     const EkfConfig k = to_core(cfg);
     const int W = (int)((N + 63) / 64);
     const dim3 grid((unsigned)B), block((unsigned)(W * 64));

@@ -101,15 +101,16 @@ namespace gsf {
 // trajectory-major launches (called from gsf_ekf.hip's C entry points)
 int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
-                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
+                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
+                    const int64_t* offsets)
 {
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
-    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N };
+    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
     // Default: one pose per lane.  The two-poses-per-lane build (ekf_variant 5) executes ~29 % fewer VALU instructions but
     // measured slower on MI355X (C3 K4 3.18 vs 2.84 ms, C2 44 vs 21 us: 177 vs 155 VGPRs -> 2 instead of 3 waves/SIMD, and
     // 58 % of its wave time in s_waitcnt); it stays opt-in until that is understood.
-    const bool one_per_lane = ctx->ekf_variant != 5;
+    const bool one_per_lane = ctx->ekf_variant != 5 || offsets != nullptr;
     if (pipeline) {
         if (one_per_lane) hipLaunchKernelGGL(ekf_wave_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
         else hipLaunchKernelGGL(ekf_wave2_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);

@@ -50,7 +50,8 @@ int ensure_scratch(gsf_ctx* ctx, size_t bytes);
 // wave-per-trajectory K4 / fused pipeline for the trajectory-major layout (gsf_ekf_wave.hip)
 int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
-                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
+                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
+                    const int64_t* offsets = nullptr);
 
 // wave-per-chunk / block-per-trajectory variant for small batches of short tracks (gsf_ekf_block.hip), N <= 1024
 int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,

@@ -71,7 +71,15 @@ struct WaveArgs {
     double* R; double* t; double* s;              // pipeline outputs (may be null)
     double* pos_out; double* quat_out; int32_t* status;
     int64_t B, N;
+    const int64_t* offsets;                       // ragged batches: trajectory b = rows offsets[b]..offsets[b+1] (else b*N.., N rows)
 };
+
+// first row and length of trajectory b
+__device__ __forceinline__ void traj_span(const WaveArgs& a, int64_t b, int64_t& base, int64_t& n)
+{
+    if (a.offsets) { base = a.offsets[b]; n = a.offsets[b + 1] - base; }
+    else { base = b * a.N; n = a.N; }
+}
 
 struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
 
@@ -96,13 +104,13 @@ __device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, co
 template <bool PIPELINE>
 __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b, const int lane, Vec3& p0_out, Quat& q0_out, int32_t& fit_out)
 {
-    const int64_t N = a.N;
-    const double* __restrict__ posb = a.pos + b * N * 3;
-    const double* __restrict__ quatb = a.quat + b * N * 4;
-    const double* __restrict__ gpsb = a.gps + b * N * 3;
-    const uint8_t* __restrict__ valb = a.valid + b * N;
-    double* __restrict__ pob = a.pos_out + b * N * 3;
-    double* __restrict__ qob = a.quat_out + b * N * 4;
+    int64_t base, N; traj_span(a, b, base, N);
+    const double* __restrict__ posb = a.pos + base * 3;
+    const double* __restrict__ quatb = a.quat + base * 4;
+    const double* __restrict__ gpsb = a.gps + base * 3;
+    const uint8_t* __restrict__ valb = a.valid + base;
+    double* __restrict__ pob = a.pos_out + base * 3;
+    double* __restrict__ qob = a.quat_out + base * 4;
     // ------------------------------------------------------------------ initial pose
     Vec3 p0; Quat q0;
     int32_t fit = 0;
@@ -184,14 +192,15 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
 template <bool PIPELINE>
 __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane)
 {
-    const int64_t N = a.N;
-    const double* __restrict__ tsb = a.ts + b * N;
-    const double* __restrict__ posb = a.pos + b * N * 3;
-    const double* __restrict__ quatb = a.quat + b * N * 4;
-    const double* __restrict__ gpsb = a.gps + b * N * 3;
-    const uint8_t* __restrict__ valb = a.valid + b * N;
-    double* __restrict__ pob = a.pos_out + b * N * 3;
-    double* __restrict__ qob = a.quat_out + b * N * 4;
+    int64_t base, N; traj_span(a, b, base, N);
+    if (N <= 0) { if (lane == 0 && a.status) a.status[b] = 0; return; }              // empty track (ref :835)
+    const double* __restrict__ tsb = a.ts + base;
+    const double* __restrict__ posb = a.pos + base * 3;
+    const double* __restrict__ quatb = a.quat + base * 4;
+    const double* __restrict__ gpsb = a.gps + base * 3;
+    const uint8_t* __restrict__ valb = a.valid + base;
+    double* __restrict__ pob = a.pos_out + base * 3;
+    double* __restrict__ qob = a.quat_out + base * 4;
 
     Vec3 p0; Quat q0; int32_t fit = 0;
     if (!wave_prelude<PIPELINE>(a, b, lane, p0, q0, fit)) return;

@@ -167,6 +167,14 @@ GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const doub
                                 const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
                                 double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
 
+/* ragged forms (trajectories of different lengths): flat [total][C] arrays, trajectory b = rows offsets[b]..offsets[b+1] */
+GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                    const uint8_t *valid, const int64_t *offsets, const double *init_pos, const double *init_quat,
+                                    const gsf_ekf_config *cfg, int64_t B, double *pos_out, double *quat_out, int32_t *status);
+GSF_API int gsf_fuse_pipeline_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                         const uint8_t *valid, const int64_t *offsets, const gsf_ekf_config *cfg, int64_t B, double *R,
+                                         double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
+
 /* ---- time alignment (dynamic_time_alignment, EKFGPSSLAM.py:325-387) ------------------------------ */
 /* B trajectories: SLAM stamps slam_t[slam_offsets[b]..), GNSS fixes gps_t / gps_p[.][3] at gps_offsets (any order, duplicates
    allowed: stable sort + first-of-equal-stamps).  Per gap-free segment (gap > max_gps_gap_threshold splits): not-a-knot cubic

@@ -566,3 +566,31 @@ def test_run_fusion_headless_driver(E, golden, tmp_path):
     assert (tmp_path / "traj_corrected_utm.txt").exists() and (tmp_path / "traj_corrected_wgs84.txt").exists()
     w = np.loadtxt(tmp_path / "traj_corrected_wgs84.txt", skiprows=1)
     assert abs(w[0, 1] - 8.395) < 1e-2 and abs(w[0, 2] - 49.0336) < 1e-2             # lon, lat of KITTI-04
+
+
+def test_ragged_batch_vs_oracle(B, orc):
+    """Trajectories of different lengths in one launch (flat arrays + offsets), incl. lengths 0, 1, 2, 63, 64, 65."""
+    import torch
+    lens = [271, 0, 1, 2, 63, 64, 65, 128, 129, 400, 1000, 33, 700]
+    parts = [B.TrajectoryBatch.synthetic(1, max(n, 1), layout=0, seed=31, traj0=k).host_traj_major() for k, n in enumerate(lens)]
+    cat = lambda key, n_: np.concatenate([p[key][0][:n] for p, n in zip(parts, lens)]) if n_ else None
+    ts, pos, quat, gps, valid = (cat(k, 1) for k in ("ts", "pos", "quat", "gps", "valid"))
+    ip = np.stack([p["init_pos"][0] for p in parts]); iq = np.stack([p["init_quat"][0] for p in parts])
+    offs = np.cumsum([0] + lens).astype(np.int64)
+    d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a)).to(dt).cuda()
+    po, qo, st = B.ekf_fuse_ragged(d(ts), d(pos), d(quat), d(gps), d(valid, torch.uint8), d(offs, torch.int64), d(ip), d(iq))
+    pp, qp, stp, R, t, s = B.fuse_pipeline_ragged(d(ts), d(pos), d(quat), d(gps), d(valid, torch.uint8), d(offs, torch.int64))
+    torch.cuda.synchronize()
+    po, qo, st, pp, stp = po.cpu().numpy(), qo.cpu().numpy(), st.cpu().numpy(), pp.cpu().numpy(), stp.cpu().numpy()
+    for k, n in enumerate(lens):
+        sl = slice(offs[k], offs[k + 1])
+        if n == 0:
+            assert st[k] == 0
+            continue
+        ro, rq, rs = orc.apply_ekf_correction_aligned(ts[sl], pos[sl], quat[sl], gps[sl], valid[sl], ip[k], iq[k], return_status=True)
+        assert np.abs(po[sl] - ro).max() < POS_TOL and np.abs(qo[sl] - rq).max() < Q_TOL and st[k] == rs, (k, n)
+        rp, rqq, rst, _, _, _ = orc.fuse_pipeline_batch(ts[sl][None], pos[sl][None], quat[sl][None], gps[sl][None], valid[sl][None])
+        if np.isfinite(rp).all():
+            assert np.abs(pp[sl] - rp[0]).max() < 1e-6 and (stp[k] & 0xff) == (rst[0] & 0xff), (k, n)
+        else:
+            assert np.isnan(pp[sl]).all() and (stp[k] >> 8) == 1, (k, n)          # fewer than 3 valid rows: the fit is None
