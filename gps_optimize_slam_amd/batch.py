@@ -219,3 +219,11 @@ def ekf_fuse_ragged(ts, pos, quat, gps, valid, offsets, init_pos, init_quat, con
     check(_lib.load().gsf_ekf_fuse_ragged_dev(context().handle, _p(ts), _p(pos), _p(quat), _p(gps), _p(valid), _p(offsets), _p(init_pos),
                                               _p(init_quat), C.byref(cfg), B, _p(po), _p(qo), _p(st)))
     return po, qo, st
+
+
+def geodetic_to_enu_batch(lat, lon, alt, offsets, ref_llh):
+    """WGS84 geodetic -> local ENU about ref_llh (B,3) per trajectory (device tensors).  Offered in addition to UTM."""
+    B = offsets.numel() - 1
+    e, n, u = torch.empty_like(lat), torch.empty_like(lat), torch.empty_like(lat)
+    check(_lib.load().gsf_geodetic_to_enu_batch_dev(context().handle, _p(lat), _p(lon), _p(alt), _p(offsets), _p(ref_llh), B, _p(e), _p(n), _p(u)))
+    return e, n, u

@@ -346,4 +346,33 @@ GSF_HD void utm_inverse_point(const TmConsts& c, double easting, double northing
     lon_deg = lam * r2d + lon0_deg;
 }
 
+// ---------------------------------------------------------------------------------------
+// WGS84 geodetic (deg, deg, m) -> local East-North-Up about a reference point (offered in ADDITION to UTM: the reference's
+// pipeline projects with UTM, BASELINE.json's north star words it as "WGS84 -> local ENU")
+// ---------------------------------------------------------------------------------------
+struct EnuFrame { double x0, y0, z0, sl, cl, sp, cp; };      // ECEF of the origin, sin/cos of its lon / lat
+GSF_HD void geodetic_to_ecef(double lat_deg, double lon_deg, double h, double& x, double& y, double& z)
+{
+    const double a = 6378137.0, f = 1.0 / 298.257223563, e2 = f * (2.0 - f), d2r = 0.017453292519943295769;
+    const double sp = sin(lat_deg * d2r), cp = cos(lat_deg * d2r), sl = sin(lon_deg * d2r), cl = cos(lon_deg * d2r);
+    const double Nn = a / sqrt(1.0 - e2 * sp * sp);
+    x = (Nn + h) * cp * cl; y = (Nn + h) * cp * sl; z = (Nn * (1.0 - e2) + h) * sp;
+}
+GSF_HD EnuFrame enu_frame(double lat0_deg, double lon0_deg, double h0)
+{
+    const double d2r = 0.017453292519943295769;
+    EnuFrame f;
+    geodetic_to_ecef(lat0_deg, lon0_deg, h0, f.x0, f.y0, f.z0);
+    f.sl = sin(lon0_deg * d2r); f.cl = cos(lon0_deg * d2r); f.sp = sin(lat0_deg * d2r); f.cp = cos(lat0_deg * d2r);
+    return f;
+}
+GSF_HD void geodetic_to_enu_point(const EnuFrame& f, double lat_deg, double lon_deg, double h, double& e, double& n, double& u)
+{
+    double x, y, z; geodetic_to_ecef(lat_deg, lon_deg, h, x, y, z);
+    const double dx = x - f.x0, dy = y - f.y0, dz = z - f.z0;
+    e = -f.sl * dx + f.cl * dy;
+    n = -f.sp * f.cl * dx - f.sp * f.sl * dy + f.cp * dz;
+    u = f.cp * f.cl * dx + f.cp * f.sl * dy + f.sp * dz;
+}
+
 }  // namespace gsf

@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256) void utm_kernel(const double* __restrict__ a, 
     }
 }
 
+// geodetic -> ENU about a per-trajectory origin (ref_llh[b] = lat0, lon0, h0), lane per point
+__global__ __launch_bounds__(256) void enu_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ alt,
+                                                  const int64_t* __restrict__ offsets, const double* __restrict__ ref_llh,
+                                                  double* __restrict__ e, double* __restrict__ n, double* __restrict__ u)
+{
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    const EnuFrame f = enu_frame(ref_llh[b * 3], ref_llh[b * 3 + 1], ref_llh[b * 3 + 2]);
+    for (int64_t i = i0 + blockIdx.y * blockDim.x + threadIdx.x; i < i1; i += (int64_t)blockDim.x * gridDim.y) {
+        double ee, nn, uu;
+        geodetic_to_enu_point(f, lat[i], lon[i], alt[i], ee, nn, uu);
+        e[i] = ee; n[i] = nn; u[i] = uu;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -102,6 +117,18 @@ int gsf_utm_inverse_batch_dev(gsf_ctx* ctx, const double* easting, const double*
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(utm_kernel<true>, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, easting, northing, offsets, zone, south, lat, lon);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_geodetic_to_enu_batch_dev(gsf_ctx* ctx, const double* lat, const double* lon, const double* alt, const int64_t* offsets,
+                                  const double* ref_llh, int64_t B, double* east, double* north, double* up)
+{
+    GSF_REQUIRE(ctx && offsets && ref_llh, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(enu_kernel, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, lat, lon, alt, offsets, ref_llh, east, north, up);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -115,6 +115,12 @@ GSF_API int gsf_utm_forward(gsf_ctx *ctx, const double *lat_deg, const double *l
 GSF_API int gsf_utm_inverse(gsf_ctx *ctx, const double *easting, const double *northing, int64_t n, int32_t zone, int32_t south,
                     double *lat_deg, double *lon_deg);
 
+/* WGS84 geodetic -> local East-North-Up about a per-trajectory origin ref_llh[B][3] = (lat0 deg, lon0 deg, h0 m).  Offered in
+   addition to UTM: the reference's pipeline projects with UTM (EKFGPSSLAM.py:266-271); BASELINE.json words the step as
+   "WGS84 -> local ENU". */
+GSF_API int gsf_geodetic_to_enu_batch_dev(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const double *alt, const int64_t *offsets,
+                                          const double *ref_llh, int64_t B, double *east, double *north, double *up);
+
 /* ---- K2: Sim3 / Umeyama (compute_sim3_transform, EKFGPSSLAM.py:428-459) ------------------- */
 /* B ragged point sets: src/dst are [total][3]; offsets int64[B+1].  Optional `mask` (uint8[total], may be NULL)
    selects the rows that take part (used for "valid GNSS only" fits).  Outputs R[B][9] (row-major), t[B][3],

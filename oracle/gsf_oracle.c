@@ -987,5 +987,25 @@ ORC_API void orc_dynamic_time_alignment(const double *slam_t, int64_t ns, const 
     free(ord); free(tt); free(ut); free(up);
 }
 
+
+/* WGS84 geodetic -> local ENU about (lat0, lon0, h0): textbook ECEF difference rotated into the tangent frame.  Not a
+ * reference function (the reference projects with UTM); checker for the product's additional ENU kernel. */
+ORC_API void orc_geodetic_to_enu(const double *lat_deg, const double *lon_deg, const double *alt, int64_t n, double lat0, double lon0,
+                                 double h0, double *e, double *nn, double *u)
+{
+    const long double a = 6378137.0L, f = 1.0L / 298.257223563L, e2 = f * (2.0L - f), d2r = 3.14159265358979323846264338327950288L / 180.0L;
+    long double sp0 = sinl(lat0 * d2r), cp0 = cosl(lat0 * d2r), sl0 = sinl(lon0 * d2r), cl0 = cosl(lon0 * d2r);
+    long double N0 = a / sqrtl(1.0L - e2 * sp0 * sp0);
+    long double x0 = (N0 + h0) * cp0 * cl0, y0 = (N0 + h0) * cp0 * sl0, z0 = (N0 * (1.0L - e2) + h0) * sp0;
+    for (int64_t i = 0; i < n; ++i) {
+        long double sp = sinl(lat_deg[i] * d2r), cp = cosl(lat_deg[i] * d2r), sl = sinl(lon_deg[i] * d2r), cl = cosl(lon_deg[i] * d2r);
+        long double Nn = a / sqrtl(1.0L - e2 * sp * sp);
+        long double dx = (Nn + alt[i]) * cp * cl - x0, dy = (Nn + alt[i]) * cp * sl - y0, dz = (Nn * (1.0L - e2) + alt[i]) * sp - z0;
+        e[i] = (double)(-sl0 * dx + cl0 * dy);
+        nn[i] = (double)(-sp0 * cl0 * dx - sp0 * sl0 * dy + cp0 * dz);
+        u[i] = (double)(cp0 * cl0 * dx + cp0 * sl0 * dy + sp0 * dz);
+    }
+}
+
 /* layout probe so the ctypes mirror of orc_config can be checked */
 ORC_API int orc_config_size(void) { return (int)sizeof(orc_config); }

@@ -83,6 +83,8 @@ def lib():
         L.orc_utm_forward.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
         L.orc_utm_inverse.restype = None
         L.orc_utm_inverse.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+        L.orc_geodetic_to_enu.restype = None
+        L.orc_geodetic_to_enu.argtypes = [f64p, f64p, f64p, C.c_int64, C.c_double, C.c_double, C.c_double, f64p, f64p, f64p]
         L.orc_umeyama.restype = C.c_int
         L.orc_umeyama.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.POINTER(C.c_double)]
         L.orc_sim3_ransac.restype = C.c_int
@@ -158,6 +160,14 @@ def utm_inverse(easting, northing, zone, south):
     lat, lon = np.empty_like(e), np.empty_like(e)
     lib().orc_utm_inverse(e, n, e.size, int(zone), int(bool(south)), lat, lon)
     return lat, lon
+
+
+def geodetic_to_enu(lat_deg, lon_deg, alt, lat0, lon0, h0):
+    """Checker for the product's additional ENU kernel (80-bit long double ECEF differences)."""
+    lat, lon, al = _a(lat_deg).ravel(), _a(lon_deg).ravel(), _a(alt).ravel()
+    e, n, u = np.empty_like(lat), np.empty_like(lat), np.empty_like(lat)
+    lib().orc_geodetic_to_enu(lat, lon, al, lat.size, float(lat0), float(lon0), float(h0), e, n, u)
+    return e, n, u
 
 
 # ---- EKFGPSSLAM.py:389-467 ---------------------------------------------------

@@ -594,3 +594,43 @@ def test_ragged_batch_vs_oracle(B, orc):
             assert np.abs(pp[sl] - rp[0]).max() < 1e-6 and (stp[k] & 0xff) == (rst[0] & 0xff), (k, n)
         else:
             assert np.isnan(pp[sl]).all() and (stp[k] >> 8) == 1, (k, n)          # fewer than 3 valid rows: the fit is None
+
+
+def test_geodetic_to_enu_kernel(B, orc, golden):
+    """The additional ENU projection (north star wording): vs the oracle's long-double ECEF form, and vs UTM locally (a tangent-plane
+    frame and a conformal projection agree to ~1e-3 relative over a few hundred metres after removing grid convergence/scale)."""
+    import torch
+    g = golden("c1_combined.npz")
+    lat, lon, alt = g["lat"], g["lon"], g["alt"]
+    offs = torch.tensor([0, len(lat)], dtype=torch.int64).cuda()
+    ref = torch.tensor([[lat[0], lon[0], alt[0]]], dtype=torch.float64).cuda()
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    e, n, u = B.geodetic_to_enu_batch(d(lat), d(lon), d(alt), offs, ref)
+    eo, no, uo = orc.geodetic_to_enu(lat, lon, alt, lat[0], lon[0], alt[0])
+    # the double ECEF difference cancels ~6.4e6 m coordinates: one ulp there is 9.3e-10 m and a handful of roundings add up
+    np.testing.assert_allclose(e.cpu().numpy(), eo, atol=1e-8, rtol=0)
+    np.testing.assert_allclose(n.cpu().numpy(), no, atol=1e-8, rtol=0)
+    np.testing.assert_allclose(u.cpu().numpy(), uo, atol=1e-8, rtol=0)
+    assert abs(eo[0]) < 1e-9 and abs(no[0]) < 1e-9 and abs(uo[0]) < 1e-9
+    # path length agrees with the UTM track to the projection scale (k ~ 0.9996..1.0004) over this ~400 m drive
+    d_enu = np.hypot(np.diff(eo), np.diff(no)).sum(); d_utm = np.hypot(np.diff(g["utm"][:, 0]), np.diff(g["utm"][:, 1])).sum()
+    assert abs(d_enu / d_utm - 1.0) < 1e-3
+
+
+def test_capi_error_paths(B):
+    """Error behaviour of the boundary: bad arguments return GSF_ERR_INVALID_ARG with a message (no launch, no crash)."""
+    import ctypes as C
+    import torch
+    from gps_optimize_slam_amd import _lib
+    L = _lib.load(); h = B.context().handle
+    x = torch.zeros(64, dtype=torch.float64, device="cuda")
+    offs = torch.tensor([0, 8], dtype=torch.int64, device="cuda")
+    assert L.gsf_utm_forward_batch_dev(h, x.data_ptr(), x.data_ptr(), None, None, None, 1, x.data_ptr(), x.data_ptr()) == 1
+    assert "NULL" in _lib.last_error()
+    assert L.gsf_utm_forward_batch_dev(None, x.data_ptr(), x.data_ptr(), offs.data_ptr(), None, None, 1, x.data_ptr(), x.data_ptr()) == 1
+    assert L.gsf_geodetic_to_enu_batch_dev(h, x.data_ptr(), x.data_ptr(), x.data_ptr(), offs.data_ptr(), x.data_ptr(), -1, x.data_ptr(), x.data_ptr(), x.data_ptr()) == 1
+    assert L.gsf_set_option(h, b"no_such_option", 1) != 0
+    with pytest.raises(_lib.GsfError):
+        _lib.check(L.gsf_set_option(h, b"no_such_option", 1))
+    # B == 0 is a no-op success on every batched entry
+    assert L.gsf_utm_forward_batch_dev(h, None, None, offs.data_ptr(), offs.data_ptr(), offs.data_ptr(), 0, None, None) == 0

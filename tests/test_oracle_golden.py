@@ -306,3 +306,27 @@ def test_utm_zone_formula():
     assert orc.auto_utm_projection(np.array([1.0]), np.array([0.0]))[1] == ""
     with pytest.raises(ValueError):
         orc.auto_utm_projection(np.array([]), np.array([]))
+
+
+def test_enu_checker_vs_independent_form():
+    """The ENU checker (long-double ECEF) against an independent numpy double evaluation and two closed forms."""
+    rng = np.random.default_rng(5)
+    lat0, lon0, h0 = 48.98, 8.39, 115.0
+    lat = lat0 + rng.normal(0, 2e-3, 500); lon = lon0 + rng.normal(0, 3e-3, 500); alt = h0 + rng.normal(0, 5.0, 500)
+    e, n, u = orc.geodetic_to_enu(lat, lon, alt, lat0, lon0, h0)
+    a, f = 6378137.0, 1 / 298.257223563
+    e2 = f * (2 - f)
+
+    def ecef(la, lo, h):
+        la, lo = np.radians(la), np.radians(lo)
+        N = a / np.sqrt(1 - e2 * np.sin(la) ** 2)
+        return np.stack([(N + h) * np.cos(la) * np.cos(lo), (N + h) * np.cos(la) * np.sin(lo), (N * (1 - e2) + h) * np.sin(la)], -1)
+    d = ecef(lat, lon, alt) - ecef(lat0, lon0, h0)
+    p0, l0 = np.radians(lat0), np.radians(lon0)
+    R = np.array([[-np.sin(l0), np.cos(l0), 0], [-np.sin(p0) * np.cos(l0), -np.sin(p0) * np.sin(l0), np.cos(p0)],
+                  [np.cos(p0) * np.cos(l0), np.cos(p0) * np.sin(l0), np.sin(p0)]])
+    enu = d @ R.T
+    np.testing.assert_allclose(np.stack([e, n, u], -1), enu, atol=5e-9, rtol=0)     # double cancellation in the 6.4e6 m ECEF difference
+    # closed forms: a pure height change moves along Up only; the origin maps to 0
+    e1, n1, u1 = orc.geodetic_to_enu([lat0, lat0], [lon0, lon0], [h0, h0 + 10.0], lat0, lon0, h0)
+    np.testing.assert_allclose([e1[0], n1[0], u1[0], e1[1], n1[1], u1[1]], [0, 0, 0, 0, 0, 10.0], atol=1e-9)
