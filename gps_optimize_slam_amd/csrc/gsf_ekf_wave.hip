@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void ekf_wave2_kernel(WaveArgs a, EkfConfig cfg
     const int64_t b = blockIdx.x, N = a.N;
     TrajPtrs T{ a.ts + b * N, a.pos + b * N * 3, a.quat + b * N * 4, a.gps + b * N * 3, a.valid + b * N, a.pos_out + b * N * 3, a.quat_out + b * N * 4, N };
     Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, lane, p0, q0, fit)) return;
+    if (!wave_prelude<PIPELINE>(a, b, b * N, N, lane, p0, q0, fit)) return;
     WaveCarry C;
     C.q = ekf_normalize(q0); C.p = p0;                                   // ref :842, :683
     C.P[0] = cfg.P0[0]; C.P[1] = cfg.P0[1]; C.P[2] = cfg.P0[2];
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void ekf_wave2_kernel(WaveArgs a, EkfConfig cfg
         nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, lane, N);
         nx1 = nx0;
     }
+    chunk_arrived(nx0); chunk_arrived(nx1);
     int64_t c0 = 0;
     while (N - c0 > 64) {
         ChunkIn in[2] = { nx0, nx1 };
@@ -73,12 +74,12 @@ __global__ __launch_bounds__(64) void ekf_wave2_kernel(WaveArgs a, EkfConfig cfg
         } else if (n0 < N) {
             nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, n0 + lane, N);
         }
-        process_chunk<2>(T, cfg, C, c0, in, lane);
+        process_chunk<2>(T, cfg, C, c0, in, lane, nx0, nx1);
         c0 = n0;
     }
     if (c0 < N) {
         ChunkIn in[1] = { nx0 };
-        process_chunk<1>(T, cfg, C, c0, in, lane);
+        process_chunk<1>(T, cfg, C, c0, in, lane, nx0, nx0);
     }
     if (lane == 0 && a.status) a.status[b] = (C.status | (C.prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }

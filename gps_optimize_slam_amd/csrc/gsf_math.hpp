@@ -149,11 +149,16 @@ GSF_HD void jacobi_pair(double* A, double* W, int p, int q, bool& rotated)
     double a = A[p] * A[p] + A[3 + p] * A[3 + p] + A[6 + p] * A[6 + p];
     double b = A[q] * A[q] + A[3 + q] * A[3 + q] + A[6 + q] * A[6 + q];
     double g = A[p] * A[q] + A[3 + p] * A[3 + q] + A[6 + p] * A[6 + q];
-    if (g == 0.0 || !(fabs(g) > 2.3e-16 * sqrt(a * b))) return;
+    if (g == 0.0 || !(g * g > 5.29e-32 * (a * b))) return;           // |g| <= 2.3e-16 sqrt(a b): columns already orthogonal
     rotated = true;
-    double zeta = (b - a) / (2.0 * g);
-    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+    // rotation angle without divisions:  zeta = (b-a)/(2g),  t = tan = sign(zeta) / (|zeta| + sqrt(1 + zeta^2))
+    //                                                         =  sign(d) h / (|d| + sqrt(d^2 + h^2)),  d = b - a, h = 2 g
+    const double d = b - a, h = 2.0 * g;
+    const double rad = d * d + h * h;
+    // with w = |d| + sqrt(d^2 + h^2):  t = sign(d) h / w,  cos = w / sqrt(w^2 + h^2),  sin = sign(d) h / sqrt(w^2 + h^2)
+    const double w = fabs(d) + rad * fast_rsqrt(rad);
+    const double rs = fast_rsqrt(w * w + h * h);
+    const double cs = w * rs, sn = ((d < 0.0) ? -h : h) * rs;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double x = A[i * 3 + p], y = A[i * 3 + q];

@@ -83,27 +83,27 @@ template <int PPL> __device__ __forceinline__ bool bit_at(const Masks<PPL>& a, i
     return ((m >> (pos / PPL)) & 1ull) != 0ull;
 }
 
-// value of sub-pose `sub` (wave-uniform) of lane `src` (wave-uniform), broadcast
-template <int PPL> __device__ __forceinline__ double pick_bcast(const double* v, int pos)
+// The pick helpers take the sub-pose values as SCALARS (v0 = sub-pose 0, v1 = sub-pose PPL-1), never as a pointer to a small
+// array: LLVM folds select(c, load a[1], load a[0]) into load a[c], and the array then lives in scratch / LDS.
+// value at the wave-uniform position `pos` (lane pos / PPL, sub-pose pos % PPL), broadcast
+template <int PPL> __device__ __forceinline__ double pick_bcast(double v0, double v1, int pos)
 {
-    double x = v[0];
-#pragma unroll
-    for (int j = 1; j < PPL; ++j) x = (pos % PPL == j) ? v[j] : x;
+    static_assert(PPL <= 2, "pick helpers are written for one or two poses per lane");
+    const double x = (PPL > 1 && (pos % PPL) == 1) ? v1 : v0;
     return lane_bcast(x, pos / PPL);
 }
-// value at a per-lane position (lane and sub differ per lane): one bpermute per sub-pose array + select
-template <int PPL> __device__ __forceinline__ double pick_shfl(const double* v, int pos)
+// value at a per-lane position (lane and sub-pose differ per lane): one bpermute per sub-pose + select
+template <int PPL> __device__ __forceinline__ double pick_shfl(double v0, double v1, int pos)
 {
-    double x = shidx(v[0], pos / PPL);
-#pragma unroll
-    for (int j = 1; j < PPL; ++j) { const double y = shidx(v[j], pos / PPL); x = (pos % PPL == j) ? y : x; }
+    double x = shidx(v0, pos / PPL);
+    if (PPL > 1) { const double y = shidx(v1, pos / PPL); x = ((pos % PPL) == 1) ? y : x; }
     return x;
 }
 
 // One chunk.  c0 = index of the chunk's first pose.  `in` = the poses of this lane (already loaded).
 template <int PPL>
 __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig& cfg, WaveCarry& C, const int64_t c0, const ChunkIn* in,
-                                              const int lane)
+                                              const int lane, const ChunkIn& nx0, const ChunkIn& nx1)
 {
     const int64_t N = T.N;
     const int CH = 64 * PPL;
@@ -306,11 +306,6 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
 #pragma unroll
     for (int j = 0; j < PPL; ++j) { xo[j][0] = xl[j][0]; xo[j][1] = xl[j][1]; xo[j][2] = xl[j][2]; }
     if (any(rts_m)) {
-        double dv[3][PPL], pv[3][PPL];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) { dv[c][j] = dcorr[j][c]; pv[c][j] = Pm[j][c]; }
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
             const int pos = lane * PPL + j;
@@ -319,7 +314,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             const bool in_run = active[j] && !av[j] && nr >= 0 && bit_at<PPL>(rts_m, nrc);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double dr = pick_shfl<PPL>(dv[c], nrc), pr = pick_shfl<PPL>(pv[c], nrc);
+                const double dr = pick_shfl<PPL>(dcorr[0][c], dcorr[PPL - 1][c], nrc), pr = pick_shfl<PPL>(Pm[0][c], Pm[PPL - 1][c], nrc);
                 if (in_run) xo[j][c] = xl[j][c] + Pf[j][c] * fast_rcp(pr) * dr;
             }
         }
@@ -329,7 +324,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             if (r1 >= 0 && bit_at<PPL>(rts_m, r1)) {
                 double dr[3], ipr[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { dr[c] = pick_bcast<PPL>(dv[c], r1); ipr[c] = fast_rcp(pick_bcast<PPL>(pv[c], r1)); }
+                for (int c = 0; c < 3; ++c) { dr[c] = pick_bcast<PPL>(dcorr[0][c], dcorr[PPL - 1][c], r1); ipr[c] = fast_rcp(pick_bcast<PPL>(Pm[0][c], Pm[PPL - 1][c], r1)); }
                 double acc = 0.0;                                         // sum of dt over (ostart, k]
                 for (int64_t k0 = (C.ostart / 64) * 64; k0 < c0; k0 += 64) {
                     const int64_t k = k0 + lane;
@@ -353,15 +348,10 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         }
     }
 
-    // ---- stores (PPL consecutive poses per lane)
+    // ---- output rows (stored at the bottom, after the prefetched rows have been waited for: see chunk_arrived)
+    double orow[PPL][3];
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-        if (active[j]) {
-            const int64_t i = c0 + (int64_t)lane * PPL + j;
-            T.pos_out[i * 3] = C.p.x + xo[j][0]; T.pos_out[i * 3 + 1] = C.p.y + xo[j][1]; T.pos_out[i * 3 + 2] = C.p.z + xo[j][2];
-            T.quat_out[i * 4] = qi[j].x; T.quat_out[i * 4 + 1] = qi[j].y; T.quat_out[i * 4 + 2] = qi[j].z; T.quat_out[i * 4 + 3] = qi[j].w;
-        }
-    }
+    for (int j = 0; j < PPL; ++j) { orow[j][0] = C.p.x + xo[j][0]; orow[j][1] = C.p.y + xo[j][1]; orow[j][2] = C.p.z + xo[j][2]; }
 
     // ---- carry to the next chunk, from the last active position Lp
     const bool open = !bit_at<PPL>(a_m, Lp);                              // the chunk ends inside an outage
@@ -370,17 +360,15 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         if (s >= 0) {
             C.ostart = c0 + s;
             C.seg_sharp = any_between<PPL>(f_m, s + 1, Lp);
-            double pf[3][PPL];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { for (int j = 0; j < PPL; ++j) pf[c][j] = Pf[j][c]; C.Pos[c] = pick_bcast<PPL>(pf[c], s); }
+            for (int c = 0; c < 3; ++c) C.Pos[c] = pick_bcast<PPL>(Pf[0][c], Pf[PPL - 1][c], s);
         } else {
             C.seg_sharp = C.seg_sharp || any_between<PPL>(f_m, 0, Lp);
         }
     }
     C.prev_avail = !open;
     {
-        double tmp[PPL];
-#define GSF_CARRY(dst, expr) { for (int j = 0; j < PPL; ++j) tmp[j] = (expr); dst = pick_bcast<PPL>(tmp, Lp); }
+#define GSF_CARRY(dst, expr) { double e0, e1; { const int j = 0; e0 = (expr); } { const int j = PPL - 1; e1 = (expr); } dst = pick_bcast<PPL>(e0, e1, Lp); }
         double x0, x1, x2;
         GSF_CARRY(x0, xl[j][0]) GSF_CARRY(x1, xl[j][1]) GSF_CARRY(x2, xl[j][2])
         Quat nq; GSF_CARRY(nq.x, qi[j].x) GSF_CARRY(nq.y, qi[j].y) GSF_CARRY(nq.z, qi[j].z) GSF_CARRY(nq.w, qi[j].w)
@@ -392,6 +380,15 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         GSF_CARRY(C.t, in[j].t)
 #undef GSF_CARRY
         C.ok = bit_at<PPL>(ok_m, Lp);
+    }
+    chunk_arrived(nx0); chunk_arrived(nx1);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {                                       // PPL consecutive poses per lane
+        if (active[j]) {
+            const int64_t i = c0 + (int64_t)lane * PPL + j;
+            T.pos_out[i * 3] = orow[j][0]; T.pos_out[i * 3 + 1] = orow[j][1]; T.pos_out[i * 3 + 2] = orow[j][2];
+            T.quat_out[i * 4] = qi[j].x; T.quat_out[i * 4 + 1] = qi[j].y; T.quat_out[i * 4 + 2] = qi[j].z; T.quat_out[i * 4 + 3] = qi[j].w;
+        }
     }
 }
 

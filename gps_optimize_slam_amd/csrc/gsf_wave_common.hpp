@@ -74,12 +74,30 @@ struct WaveArgs {
     const int64_t* offsets;                       // ragged batches: trajectory b = rows offsets[b]..offsets[b+1] (else b*N.., N rows)
 };
 
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
 // first row and length of trajectory b
 __device__ __forceinline__ void traj_span(const WaveArgs& a, int64_t b, int64_t& base, int64_t& n)
 {
-    if (a.offsets) { base = a.offsets[b]; n = a.offsets[b + 1] - base; }
-    else { base = b * a.N; n = a.N; }
+    if (a.offsets) {
+        // wave-uniform by construction (b = blockIdx.x): pin both words in SGPRs so that every address below stays scalar
+        const int64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+        base = uniform64(o0); n = uniform64(o1) - base;
+    } else { base = b * a.N; n = a.N; }
 }
+
+#ifdef GSF_CHUNK_TIMING
+// diagnostic build only (tools/chunk_timing.py): wave 0 writes (shader clock, 100 MHz clock) stamps into status[2k], status[2k+1];
+// no wave writes its real status word in this build
+#define GSF_STAMP(k) do { if (b == 0 && lane == 0 && a.status) { a.status[2 * (k)] = (int32_t)(clock64() & 0x7fffffff); a.status[2 * (k) + 1] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#define GSF_STATUS_PTR(a) ((int32_t*)nullptr)
+#else
+#define GSF_STAMP(k) do { } while (0)
+#define GSF_STATUS_PTR(a) ((a).status)
+#endif
 
 struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
 
@@ -98,13 +116,23 @@ __device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, co
 }
 
 
+// Pins the point where a prefetched chunk must have ARRIVED.  vmcnt counts loads and stores in issue order, and hipcc merges
+// control-flow paths conservatively: left alone it waits with vmcnt(0) at the loop top, i.e. for the previous chunk's STORES
+// to be acknowledged (~1 us per chunk on a latency-bound small batch).  Consuming the registers right BEFORE this chunk's
+// stores are issued makes that vmcnt(0) harmless (only the prefetch, issued a whole chunk ago, is outstanding), and the loop
+// top then has nothing pending on either edge: store latency is never waited for.
+__device__ __forceinline__ void chunk_arrived(const ChunkIn& c)
+{
+    asm volatile("" :: "v"(c.t), "v"(c.p.x), "v"(c.p.y), "v"(c.p.z), "v"(c.q.x), "v"(c.q.y), "v"(c.q.z), "v"(c.q.w), "v"(c.z.x), "v"(c.z.y), "v"(c.z.z), "v"(c.v) : "memory");
+}
+
 // Initial pose of trajectory b: either the caller's Sim3-aligned pose 0, or (PIPELINE) the Umeyama fit on the rows with valid
 // finite GNSS + Sim3 of pose 0.  Returns false (after writing NaN outputs / status) when the fit is None or pose 0's quaternion
 // is invalid -- wave-uniformly.
 template <bool PIPELINE>
-__device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b, const int lane, Vec3& p0_out, Quat& q0_out, int32_t& fit_out)
+__device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b, const int64_t base, const int64_t N, const int lane,
+                                             Vec3& p0_out, Quat& q0_out, int32_t& fit_out)
 {
-    int64_t base, N; traj_span(a, b, base, N);
     const double* __restrict__ posb = a.pos + base * 3;
     const double* __restrict__ quatb = a.quat + base * 4;
     const double* __restrict__ gpsb = a.gps + base * 3;
@@ -118,32 +146,61 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
         // K2 on the rows with valid, finite GNSS, ONE pass: moments of the data shifted by pose 0 / the first finite fix
         // (|shifted| <= track length, so the raw-moment form H = Sab - n ma mb^T loses nothing at UTM magnitudes), then K3
         // of pose 0.  Sums are per-lane partials + a DPP wave reduction.
+        // The rows are read in rounds of MOM_ROUND chunks with every load of a round issued before the first use, so a 271-pose
+        // track (the small-batch, latency-bound case) pays ONE memory round trip for the whole pass instead of one per chunk.
+        // The GNSS-side shift (first valid finite fix, wave-uniform) is found in the same pass: nothing is accumulated before it.
         const double as0 = posb[0], as1 = posb[1], as2 = posb[2];
+        const Quat qraw0{ quatb[0], quatb[1], quatb[2], quatb[3] };      // pose 0's quaternion: requested here, used after the fit
         double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
-        {   // shift for the GNSS side: the first valid finite fix of the track (wave-uniform)
-            bool found = false;
-            for (int64_t c0 = 0; c0 < N && !found; c0 += 64) {
-                const int64_t i = c0 + lane;
-                bool ok = false; double z0 = 0, z1 = 0, z2 = 0;
-                if (i < N) { z0 = gpsb[i * 3]; z1 = gpsb[i * 3 + 1]; z2 = gpsb[i * 3 + 2]; ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2)); }
-                const u64 m = __ballot(ok);
-                if (m != 0ull) { const int f = __ffsll((long long)m) - 1; bs0 = lane_bcast(z0, f); bs1 = lane_bcast(z1, f); bs2 = lane_bcast(z2, f); found = true; }
-            }
-        }
+        bool have_shift = false;
         double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
         double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int64_t i = lane; i < N; i += 64) {
-            const double z0 = gpsb[i * 3], z1 = gpsb[i * 3 + 1], z2 = gpsb[i * 3 + 2];
-            const bool ok = valb[i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
-            if (!ok) continue;
-            const double a0 = posb[i * 3] - as0, a1 = posb[i * 3 + 1] - as1, a2 = posb[i * 3 + 2] - as2;
-            const double b0 = z0 - bs0, b1 = z1 - bs1, b2 = z2 - bs2;
-            cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
-            Saa += a0 * a0 + a1 * a1 + a2 * a2;
-            Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
-            Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
-            Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
+        constexpr int MOM_ROUND = 6;
+        for (int64_t c0 = 0; c0 < N; c0 += 64 * MOM_ROUND) {
+            double pa[MOM_ROUND][3], pz[MOM_ROUND][3]; uint32_t pv[MOM_ROUND];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) {
+                if (c0 + 64 * k < N) {                                    // wave-uniform
+                    const int64_t i = c0 + 64 * k + lane, il = i < N ? i : N - 1;
+                    pa[k][0] = posb[il * 3]; pa[k][1] = posb[il * 3 + 1]; pa[k][2] = posb[il * 3 + 2];
+                    pz[k][0] = gpsb[il * 3]; pz[k][1] = gpsb[il * 3 + 1]; pz[k][2] = gpsb[il * 3 + 2];
+                    pv[k] = valb[il];
+                } else {
+                    pa[k][0] = pa[k][1] = pa[k][2] = 0.0; pz[k][0] = pz[k][1] = pz[k][2] = 0.0; pv[k] = 0u;
+                }
+            }
+            bool ok[MOM_ROUND];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k)
+                ok[k] = (c0 + 64 * k + lane < N) && pv[k] != 0 && !(isnan(pz[k][0]) || isnan(pz[k][1]) || isnan(pz[k][2]));
+            if (!have_shift) {                                            // wave-uniform, normally only in the first round
+                u64 msel = 0ull; int ksel = -1;
+#pragma unroll
+                for (int k = MOM_ROUND - 1; k >= 0; --k) { const u64 m = __ballot(ok[k]); if (m != 0ull) { msel = m; ksel = k; } }
+                if (ksel >= 0) {
+                    double v0 = pz[0][0], v1 = pz[0][1], v2 = pz[0][2];
+#pragma unroll
+                    for (int k = 1; k < MOM_ROUND; ++k) { const bool pick = (ksel == k); v0 = pick ? pz[k][0] : v0; v1 = pick ? pz[k][1] : v1; v2 = pick ? pz[k][2] : v2; }
+                    const int f = __ffsll((long long)msel) - 1;
+                    bs0 = lane_bcast(v0, f); bs1 = lane_bcast(v1, f); bs2 = lane_bcast(v2, f);
+                    have_shift = true;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) {
+                if (c0 + 64 * k < N) {                                    // wave-uniform
+                    const bool o = ok[k];
+                    const double a0 = o ? pa[k][0] - as0 : 0.0, a1 = o ? pa[k][1] - as1 : 0.0, a2 = o ? pa[k][2] - as2 : 0.0;
+                    const double b0 = o ? pz[k][0] - bs0 : 0.0, b1 = o ? pz[k][1] - bs1 : 0.0, b2 = o ? pz[k][2] - bs2 : 0.0;
+                    cnt += o ? 1.0 : 0.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
+                    Saa += a0 * a0 + a1 * a1 + a2 * a2;
+                    Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
+                    Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
+                    Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
+                }
+            }
         }
+        GSF_STAMP(2);
         const double n = wave_sum(cnt);
         double Rb[9], tb[3], sb = NAN;
         fit = SIM3_NONE;
@@ -156,9 +213,11 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
             for (int k = 0; k < 9; ++k) H[k] = wave_sum(Sab[k]) - n * ma[k / 3] * mb[k % 3];
             const double ssq = fmax(0.0, wave_sum(Saa) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
             const double sc[3] = { as0 + ma[0], as1 + ma[1], as2 + ma[2] }, dc[3] = { bs0 + mb[0], bs1 + mb[1], bs2 + mb[2] };
+            GSF_STAMP(3);
             fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);       // every lane redundantly (wave-uniform inputs)
+            GSF_STAMP(4);
         }
-        Quat qn0; const bool q0ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, qn0);
+        Quat qn0; const bool q0ok = quat_unit(qraw0, qn0);
         if (fit == SIM3_NONE || !q0ok) {                                  // wave-uniform
             for (int64_t i = lane; i < N; i += 64) {
                 pob[i * 3] = NAN; pob[i * 3 + 1] = NAN; pob[i * 3 + 2] = NAN;
@@ -167,7 +226,7 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
             if (lane == 0) {
                 for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
                 a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
-                if (a.status) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
+                if (GSF_STATUS_PTR(a)) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
             }
             return false;
         }
@@ -175,10 +234,11 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
             for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
             a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
         }
-        const double x = posb[0], y = posb[1], z = posb[2];
+        const double x = as0, y = as1, z = as2;
         p0 = Vec3{ sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + tb[0], sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + tb[1],
                    sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + tb[2] };   // ref :464
         q0 = quat_mul(quat_from_matrix(Rb), qn0);                        // ref :465-466
+        GSF_STAMP(5);
     } else {
         p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
         q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };
@@ -192,8 +252,9 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
 template <bool PIPELINE>
 __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane)
 {
+    GSF_STAMP(0);
     int64_t base, N; traj_span(a, b, base, N);
-    if (N <= 0) { if (lane == 0 && a.status) a.status[b] = 0; return; }              // empty track (ref :835)
+    if (N <= 0) { if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = 0; return; }              // empty track (ref :835)
     const double* __restrict__ tsb = a.ts + base;
     const double* __restrict__ posb = a.pos + base * 3;
     const double* __restrict__ quatb = a.quat + base * 4;
@@ -202,27 +263,32 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
 
+    // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
+    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, lane, p0, q0, fit)) return;
+    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) return;
+    GSF_STAMP(6);
 
     // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
     Quat cq = ekf_normalize(q0);                                         // ref :842, :683
     Vec3 cp = p0;
     double cP[3] = { cfg.P0[0], cfg.P0[1], cfg.P0[2] };
-    bool c_prev_avail = valb[0] != 0;                                    // ref :848 (raw mask)
     int64_t c_ostart = 0;                                                // ref :861-862
     bool c_seg_sharp = false;
     double cPos[3] = { cP[0], cP[1], cP[2] };                            // P_f at the first pose of the open outage
-    Vec3 c_po{ posb[0], posb[1], posb[2] };
-    Quat c_r; bool c_ok = quat_unit(Quat{ quatb[0], quatb[1], quatb[2], quatb[3] }, c_r);
-    double c_t = tsb[0];
-    int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
     int same_axis[3] = { -1, -1, -1 };                                   // wave-uniform: axis c repeats axis same_axis[c]
     if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
     if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
     else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
 
-    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
+    chunk_arrived(nxt);
+    GSF_STAMP(7);
+    // "previous original pose" of pose 0 is pose 0 itself (ref :858): taken from lane 0 of the chunk that has just arrived
+    bool c_prev_avail = __builtin_amdgcn_readlane((int)nxt.v, 0) != 0;   // ref :848 (raw mask)
+    Vec3 c_po = lane_bcast(nxt.p, 0);
+    Quat c_r; bool c_ok = quat_unit(lane_bcast(nxt.q, 0), c_r);
+    double c_t = lane_bcast(nxt.t, 0);
+    int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
     for (int64_t c0 = 0; c0 < N; c0 += 64) {
         const int64_t i = c0 + lane;
         const bool active = i < N;
@@ -397,11 +463,8 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
             }
         }
 
-        // ---- stores
-        if (active) {
-            pob[i * 3] = cp.x + xo[0]; pob[i * 3 + 1] = cp.y + xo[1]; pob[i * 3 + 2] = cp.z + xo[2];
-            qob[i * 4] = qi.x; qob[i * 4 + 1] = qi.y; qob[i * 4 + 2] = qi.z; qob[i * 4 + 3] = qi.w;
-        }
+        // ---- output rows (stored at the bottom of the iteration, after the prefetch has been waited for)
+        const double o0 = cp.x + xo[0], o1 = cp.y + xo[1], o2 = cp.z + xo[2];
 
         // ---- carry to the next 64 poses (from the last active lane L)
         const bool open = ((a_mask >> L) & 1ull) == 0ull;                // the chunk ends inside an outage
@@ -421,8 +484,14 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         cp = Vec3{ cp.x + lane_bcast(xl[0], L), cp.y + lane_bcast(xl[1], L), cp.z + lane_bcast(xl[2], L) };
         cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
         c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
+        chunk_arrived(nxt);                                              // the next chunk's rows; then this chunk's stores
+        if (active) {
+            pob[i * 3] = o0; pob[i * 3 + 1] = o1; pob[i * 3 + 2] = o2;
+            qob[i * 4] = qi.x; qob[i * 4 + 1] = qi.y; qob[i * 4 + 2] = qi.z; qob[i * 4 + 3] = qi.w;
+        }
+        GSF_STAMP(8 + (int)(c0 / 64));
     }
-    if (lane == 0 && a.status) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
+    if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }
 
 
