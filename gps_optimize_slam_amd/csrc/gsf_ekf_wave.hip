@@ -29,16 +29,30 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 }
 
 
-// Experimental form (ekf_variant 5): 128 poses per iteration (two per lane) while more than 64 poses remain, a 64-pose
-// iteration for the tail.  The prelude (fit + Sim3 of pose 0) is shared with the PPL = 1 kernel above via wave_prelude().
-template <bool PIPELINE>
-__global__ __launch_bounds__(64) void ekf_wave2_kernel(WaveArgs a, EkfConfig cfg)
+// Several poses per lane: an iteration takes 64 * P consecutive poses, P = min(PPLMAX, ceil(remaining / 64)), lane l owning the P
+// consecutive poses l*P .. l*P+P-1 (process_chunk<P>: in-lane composition, ONE set of DPP scans per iteration, in-lane
+// application).  A track of up to 64 * PPLMAX poses is a single iteration with no chunk-to-chunk carry at all.  The wave executes
+// fewer scan stages per pose the larger P is, at the price of registers and per-sub-pose bookkeeping (no next-chunk prefetch
+// here).  Opt-in only: measured slower than one pose per lane on MI355X (see launch_ekf_wave).
+template <int P>
+__device__ __forceinline__ void load_and_process(const TrajPtrs& T, const EkfConfig& cfg, WaveCarry& C, const int64_t c0, const int lane)
+{
+    ChunkIn in[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) in[j] = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, c0 + (int64_t)lane * P + j, T.N);
+    process_chunk<P>(T, cfg, C, c0, in, lane);
+}
+
+template <bool PIPELINE, int PPLMAX>
+__global__ __launch_bounds__(64) void ekf_wavep_kernel(WaveArgs a, EkfConfig cfg)
 {
     const int lane = threadIdx.x;
-    const int64_t b = blockIdx.x, N = a.N;
-    TrajPtrs T{ a.ts + b * N, a.pos + b * N * 3, a.quat + b * N * 4, a.gps + b * N * 3, a.valid + b * N, a.pos_out + b * N * 3, a.quat_out + b * N * 4, N };
+    const int64_t b = blockIdx.x;
+    int64_t base, N; traj_span(a, b, base, N);
+    if (N <= 0) { if (lane == 0 && a.status) a.status[b] = 0; return; }              // empty track (ref :835)
+    TrajPtrs T{ a.ts + base, a.pos + base * 3, a.quat + base * 4, a.gps + base * 3, a.valid + base, a.pos_out + base * 3, a.quat_out + base * 4, N };
     Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, b * N, N, lane, p0, q0, fit)) return;
+    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) return;
     WaveCarry C;
     C.q = ekf_normalize(q0); C.p = p0;                                   // ref :842, :683
     C.P[0] = cfg.P0[0]; C.P[1] = cfg.P0[1]; C.P[2] = cfg.P0[2];
@@ -53,33 +67,15 @@ __global__ __launch_bounds__(64) void ekf_wave2_kernel(WaveArgs a, EkfConfig cfg
     if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) C.same_axis[1] = 0;
     if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) C.same_axis[2] = 0;
     else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) C.same_axis[2] = 1;
-    // The poses of a chunk are loaded one iteration ahead (before the previous chunk's scans and stores are issued), so
-    // their latency is covered and the in-order vmcnt never has to drain the stores to reach them.
-    ChunkIn nx0, nx1;
-    if (N > 64) {
-        nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, 2 * (int64_t)lane, N);
-        nx1 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, 2 * (int64_t)lane + 1, N);
-    } else {
-        nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, lane, N);
-        nx1 = nx0;
-    }
-    chunk_arrived(nx0); chunk_arrived(nx1);
-    int64_t c0 = 0;
-    while (N - c0 > 64) {
-        ChunkIn in[2] = { nx0, nx1 };
-        const int64_t n0 = c0 + 128;
-        if (N - n0 > 64) {
-            nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, n0 + 2 * (int64_t)lane, N);
-            nx1 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, n0 + 2 * (int64_t)lane + 1, N);
-        } else if (n0 < N) {
-            nx0 = load_chunk(T.ts, T.pos, T.quat, T.gps, T.valid, n0 + lane, N);
-        }
-        process_chunk<2>(T, cfg, C, c0, in, lane, nx0, nx1);
-        c0 = n0;
-    }
-    if (c0 < N) {
-        ChunkIn in[1] = { nx0 };
-        process_chunk<1>(T, cfg, C, c0, in, lane, nx0, nx0);
+    for (int64_t c0 = 0; c0 < N;) {
+        const int64_t rem = N - c0;
+        const int p = rem >= 64 * PPLMAX ? PPLMAX : (int)((rem + 63) / 64);          // wave-uniform
+        if (PPLMAX >= 5 && p == 5) load_and_process<(PPLMAX >= 5 ? 5 : 1)>(T, cfg, C, c0, lane);
+        else if (PPLMAX >= 4 && p == 4) load_and_process<(PPLMAX >= 4 ? 4 : 1)>(T, cfg, C, c0, lane);
+        else if (PPLMAX >= 3 && p == 3) load_and_process<(PPLMAX >= 3 ? 3 : 1)>(T, cfg, C, c0, lane);
+        else if (PPLMAX >= 2 && p == 2) load_and_process<(PPLMAX >= 2 ? 2 : 1)>(T, cfg, C, c0, lane);
+        else load_and_process<1>(T, cfg, C, c0, lane);
+        c0 += 64 * p;
     }
     if (lane == 0 && a.status) a.status[b] = (C.status | (C.prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }
@@ -108,17 +104,26 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
-    // Default: one pose per lane.  The two-poses-per-lane build (ekf_variant 5) executes ~29 % fewer VALU instructions but
-    // measured slower on MI355X (C3 K4 3.18 vs 2.84 ms, C2 44 vs 21 us: 177 vs 155 VGPRs -> 2 instead of 3 waves/SIMD, and
-    // 58 % of its wave time in s_waitcnt); it stays opt-in until that is understood.
-    const bool one_per_lane = ctx->ekf_variant != 5 || offsets != nullptr;
-    if (pipeline) {
-        if (one_per_lane) hipLaunchKernelGGL(ekf_wave_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-        else hipLaunchKernelGGL(ekf_wave2_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-    } else {
-        if (one_per_lane) hipLaunchKernelGGL(ekf_wave_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-        else hipLaunchKernelGGL(ekf_wave2_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+    // Poses per lane (gsf_set_option "wave_ppl": 0 = automatic, 1..5 forced).  Automatic is ONE pose per lane with a register
+    // prefetch at every batch size.  The multi-pose builds (process_chunk<P>) pass the same parity tests but measured slower on
+    // MI355X everywhere: C2 K4 18.1 / 21.1 / 21.6 / 25.1 / 30.0 us for P = 1..5, and worse at large batches (2 waves or fewer per
+    // SIMD): their per-pose bookkeeping (one ballot set per sub-pose, position <-> lane arithmetic, 300-500 registers with AGPR
+    // traffic) costs more than the scan stages they save.  They stay opt-in.
+    int ppl = ctx->wave_ppl;
+    if (ctx->ekf_variant == 5) ppl = 2;                                  // historical name of the two-pose build
+    if (ppl == 0) ppl = 1;
+#define GSF_LAUNCH_WAVEP(P) do { if (pipeline) hipLaunchKernelGGL((ekf_wavep_kernel<true, P>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); \
+                                 else hipLaunchKernelGGL((ekf_wavep_kernel<false, P>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); } while (0)
+    switch (ppl) {
+    case 2: GSF_LAUNCH_WAVEP(2); break;
+    case 3: GSF_LAUNCH_WAVEP(3); break;
+    case 4: GSF_LAUNCH_WAVEP(4); break;
+    case 5: GSF_LAUNCH_WAVEP(5); break;
+    default:
+        if (pipeline) hipLaunchKernelGGL(ekf_wave_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+        else hipLaunchKernelGGL(ekf_wave_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
     }
+#undef GSF_LAUNCH_WAVEP
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -16,6 +16,7 @@ struct gsf_ctx {
     void* scratch;
     size_t scratch_bytes;
     int ekf_variant;       // tuning knob (gsf_set_option "ekf_variant")
+    int wave_ppl;          // poses per lane of the wave-per-trajectory kernels (gsf_set_option "wave_ppl"; 0 = automatic)
 };
 
 namespace gsf {

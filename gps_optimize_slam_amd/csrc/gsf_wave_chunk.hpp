@@ -26,10 +26,25 @@ struct WaveCarry {
     int same_axis[3];
 };
 
+// One ballot per sub-pose.  Scalar members with value-level selects on purpose: an array member read through a select chain
+// is folded by LLVM into a dynamically indexed load, i.e. a table in scratch (seen with four poses per lane).
 template <int PPL>
-struct Masks { u64 m[PPL]; };
+struct Masks {
+    u64 m0, m1, m2, m3, m4;
+    // always-inlined constructor: an out-of-line implicit one would keep the object's address alive through the early
+    // optimisation passes, and the select chain of get() is then folded into a dynamically indexed load from scratch
+    __device__ __forceinline__ Masks() : m0(0ull), m1(0ull), m2(0ull), m3(0ull), m4(0ull) {}
+    // pure arithmetic (no select between member loads: hipcc optimises every helper stand-alone BEFORE inlining, and would fold
+    // such a select into one dynamically indexed load -- the object then stays in scratch for good)
+    __device__ __forceinline__ u64 get(int j) const
+    {
+        return (m0 & (0ull - (u64)(j == 0))) | (m1 & (0ull - (u64)(j == 1))) | (m2 & (0ull - (u64)(j == 2))) | (m3 & (0ull - (u64)(j == 3))) |
+               (m4 & (0ull - (u64)(j == 4)));
+    }
+    __device__ __forceinline__ void set(int j, u64 v) { m0 = (j == 0) ? v : m0; m1 = (j == 1) ? v : m1; m2 = (j == 2) ? v : m2; m3 = (j == 3) ? v : m3; m4 = (j == 4) ? v : m4; }
+};
 
-template <int PPL> __device__ __forceinline__ bool any(const Masks<PPL>& a) { u64 o = 0; for (int j = 0; j < PPL; ++j) o |= a.m[j]; return o != 0ull; }
+template <int PPL> __device__ __forceinline__ bool any(const Masks<PPL>& a) { u64 o = 0; for (int j = 0; j < PPL; ++j) o |= a.get(j); return o != 0ull; }
 
 // highest position < pos whose bit is set, or -1
 template <int PPL>
@@ -40,7 +55,7 @@ __device__ __forceinline__ int last_before(const Masks<PPL>& a, int pos)
     for (int k = 0; k < PPL; ++k) {
         const int d = pos - k - 1;                           // positions lane*PPL + k <= pos-1  <=>  lane <= d / PPL
         if (d < 0) continue;
-        const u64 m = a.m[k] & bits(0, d / PPL);
+        const u64 m = a.get(k) & bits(0, d / PPL);
         if (m != 0ull) { const int c = (63 - __clzll((long long)m)) * PPL + k; best = c > best ? c : best; }
     }
     return best;
@@ -55,7 +70,7 @@ __device__ __forceinline__ int first_after(const Masks<PPL>& a, int pos)
         const int d = pos - k;                               // lane*PPL + k > pos  <=>  lane > d / PPL (d >= 0), any lane if d < 0
         const int lmin = d < 0 ? 0 : d / PPL + 1;
         if (lmin > 63) continue;
-        const u64 m = a.m[k] & ~bits(0, lmin - 1);
+        const u64 m = a.get(k) & ~bits(0, lmin - 1);
         if (m != 0ull) { const int c = (__ffsll((long long)m) - 1) * PPL + k; best = (best < 0 || c < best) ? c : best; }
     }
     return best;
@@ -71,39 +86,53 @@ __device__ __forceinline__ bool any_between(const Masks<PPL>& a, int lo, int hi)
         const int dl = lo - k, dh = hi - k;
         if (dh < 0) continue;
         const int l0 = dl <= 0 ? 0 : (dl + PPL - 1) / PPL, l1 = dh / PPL;
-        o |= a.m[k] & bits(l0, l1);
+        o |= a.get(k) & bits(l0, l1);
     }
     return o != 0ull;
 }
 template <int PPL> __device__ __forceinline__ bool bit_at(const Masks<PPL>& a, int pos)
 {
-    u64 m = a.m[0];                                          // select, never a dynamically indexed array (that would live in scratch)
-#pragma unroll
-    for (int j = 1; j < PPL; ++j) m = (pos % PPL == j) ? a.m[j] : m;
-    return ((m >> (pos / PPL)) & 1ull) != 0ull;
+    return ((a.get(pos % PPL) >> (pos / PPL)) & 1ull) != 0ull;
 }
 
-// The pick helpers take the sub-pose values as SCALARS (v0 = sub-pose 0, v1 = sub-pose PPL-1), never as a pointer to a small
-// array: LLVM folds select(c, load a[1], load a[0]) into load a[c], and the array then lives in scratch / LDS.
-// value at the wave-uniform position `pos` (lane pos / PPL, sub-pose pos % PPL), broadcast
-template <int PPL> __device__ __forceinline__ double pick_bcast(double v0, double v1, int pos)
+// The pick helpers take the sub-pose values as SEPARATE SCALAR ARGUMENTS, never as a pointer / reference / struct: hipcc
+// optimises each helper stand-alone before it is inlined, and there folds select(c, load a[1], load a[0]) into load a[c] -- the
+// caller's array then lives in scratch (or LDS) for good.
+constexpr int PPL_MAX = 5;
+// GSF_SUBS(E): the value of expression E (written in terms of `j`) for j = 0 .. 4 as five arguments; unused slots repeat j = 0
+#define GSF_SUB1(E, K) [&]() __attribute__((always_inline)) { constexpr int j = (PPL > (K)) ? (K) : 0; return (double)(E); }()
+#define GSF_SUBS(E) GSF_SUB1(E, 0), GSF_SUB1(E, 1), GSF_SUB1(E, 2), GSF_SUB1(E, 3), GSF_SUB1(E, 4)
+template <int PPL> __device__ __forceinline__ double pick_sub(double v0, double v1, double v2, double v3, double v4, int sub)
 {
-    static_assert(PPL <= 2, "pick helpers are written for one or two poses per lane");
-    const double x = (PPL > 1 && (pos % PPL) == 1) ? v1 : v0;
-    return lane_bcast(x, pos / PPL);
+    static_assert(PPL <= PPL_MAX, "at most PPL_MAX poses per lane");
+    double x = v0;
+    if (PPL > 1) x = (sub == 1) ? v1 : x;
+    if (PPL > 2) x = (sub == 2) ? v2 : x;
+    if (PPL > 3) x = (sub == 3) ? v3 : x;
+    if (PPL > 4) x = (sub == 4) ? v4 : x;
+    return x;
+}
+// value at the wave-uniform position `pos` (lane pos / PPL, sub-pose pos % PPL), broadcast
+template <int PPL> __device__ __forceinline__ double pick_bcast(double v0, double v1, double v2, double v3, double v4, int pos)
+{
+    return lane_bcast(pick_sub<PPL>(v0, v1, v2, v3, v4, pos % PPL), pos / PPL);
 }
 // value at a per-lane position (lane and sub-pose differ per lane): one bpermute per sub-pose + select
-template <int PPL> __device__ __forceinline__ double pick_shfl(double v0, double v1, int pos)
+template <int PPL> __device__ __forceinline__ double pick_shfl(double v0, double v1, double v2, double v3, double v4, int pos)
 {
-    double x = shidx(v0, pos / PPL);
-    if (PPL > 1) { const double y = shidx(v1, pos / PPL); x = ((pos % PPL) == 1) ? y : x; }
+    const int src = pos / PPL, sub = pos % PPL;
+    double x = shidx(v0, src);
+    if (PPL > 1) { const double y = shidx(v1, src); x = (sub == 1) ? y : x; }
+    if (PPL > 2) { const double y = shidx(v2, src); x = (sub == 2) ? y : x; }
+    if (PPL > 3) { const double y = shidx(v3, src); x = (sub == 3) ? y : x; }
+    if (PPL > 4) { const double y = shidx(v4, src); x = (sub == 4) ? y : x; }
     return x;
 }
 
 // One chunk.  c0 = index of the chunk's first pose.  `in` = the poses of this lane (already loaded).
 template <int PPL>
 __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig& cfg, WaveCarry& C, const int64_t c0, const ChunkIn* in,
-                                              const int lane, const ChunkIn& nx0, const ChunkIn& nx1)
+                                              const int lane)
 {
     const int64_t N = T.N;
     const int CH = 64 * PPL;
@@ -119,13 +148,13 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
     }
     Masks<PPL> act_m, ok_m;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) { act_m.m[j] = __ballot(active[j]); ok_m.m[j] = __ballot(ok[j]); }
+    for (int j = 0; j < PPL; ++j) { act_m.set(j, __ballot(active[j])); ok_m.set(j, __ballot(ok[j])); }
     // ---- previous pose of every sub-pose: sub 0 <- last sub-pose of the previous lane (lane 0: the carry), sub j <- sub j-1
     double t_pr[PPL]; Vec3 p_pr[PPL]; Quat r_pr[PPL]; bool ok_pr[PPL];
     t_pr[0] = prev_lane(C.t, in[PPL - 1].t);
     p_pr[0] = Vec3{ prev_lane(C.po.x, in[PPL - 1].p.x), prev_lane(C.po.y, in[PPL - 1].p.y), prev_lane(C.po.z, in[PPL - 1].p.z) };
     r_pr[0] = prev_lane(C.r, r[PPL - 1]);
-    ok_pr[0] = (lane == 0) ? C.ok : (((ok_m.m[PPL - 1] >> (lane - 1)) & 1ull) != 0ull);
+    ok_pr[0] = (lane == 0) ? C.ok : (((ok_m.get(PPL - 1) >> (lane - 1)) & 1ull) != 0ull);
 #pragma unroll
     for (int j = 1; j < PPL; ++j) { t_pr[j] = in[j - 1].t; p_pr[j] = in[j - 1].p; r_pr[j] = r[j - 1]; ok_pr[j] = ok[j - 1]; }
     double dt[PPL];
@@ -133,7 +162,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
     for (int j = 0; j < PPL; ++j) dt[j] = fmax(1e-6, in[j].t - t_pr[j]);                           // ref :865
     bool all_ok = C.ok;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) all_ok = all_ok && ((ok_m.m[j] & act_m.m[j]) == act_m.m[j]);
+    for (int j = 0; j < PPL; ++j) all_ok = all_ok && ((ok_m.get(j) & act_m.get(j)) == act_m.get(j));
     const bool telescope = all_ok;                                        // see gsf_ekf_wave.hip: no invalid quaternion in sight
 
     // ---- GNSS gate (ref :867-869) and the outage structure as ballots
@@ -143,9 +172,9 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
     for (int j = 0; j < PPL; ++j) {
         avail[j] = stepping[j] && vraw[j] && !(isnan(in[j].z.x) || isnan(in[j].z.y) || isnan(in[j].z.z));
         av[j] = is_init[j] ? vraw[j] : avail[j];                          // pose 0: raw mask (ref :848)
-        a_m.m[j] = __ballot(active[j] && av[j]);
+        a_m.set(j, __ballot(active[j] && av[j]));
     }
-    ap[0] = (lane == 0) ? (is_init[0] ? true : C.prev_avail) : (((a_m.m[PPL - 1] >> (lane - 1)) & 1ull) != 0ull);
+    ap[0] = (lane == 0) ? (is_init[0] ? true : C.prev_avail) : (((a_m.get(PPL - 1) >> (lane - 1)) & 1ull) != 0ull);
 #pragma unroll
     for (int j = 1; j < PPL; ++j) ap[j] = av[j - 1];
     Masks<PPL> start_m, rec_m, pair_m, f_m;
@@ -154,8 +183,8 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         const bool starts = active[j] && !av[j] && ap[j];                 // ref :875-877 (pose 0: :861)
         recovers[j] = stepping[j] && av[j] && !ap[j];                     // ref :879
         outpair[j] = stepping[j] && !av[j] && !ap[j];
-        start_m.m[j] = __ballot(starts); rec_m.m[j] = __ballot(recovers[j]); pair_m.m[j] = __ballot(outpair[j]);
-        f_m.m[j] = 0ull;
+        start_m.set(j, __ballot(starts)); rec_m.set(j, __ballot(recovers[j])); pair_m.set(j, __ballot(outpair[j]));
+        f_m.set(j, 0ull);
     }
     if (any(start_m)) C.status |= ST_HAD_OUTAGE;
     if (any(pair_m)) {                                                    // is_sharp_turn_in_segment pairs, ref :808-826
@@ -163,7 +192,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         for (int j = 0; j < PPL; ++j) {
             bool f = false;
             if (outpair[j] && in[j].t > t_pr[j]) f = !(ok_pr[j] && ok[j]) || yaw_rate_exceeds(r_pr[j], r[j], in[j].t - t_pr[j], cfg.yaw_thr_rad);
-            f_m.m[j] = __ballot(f);
+            f_m.set(j, __ballot(f));
         }
     }
     // recovery decision (ref :879-894)
@@ -180,8 +209,8 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             else { s_glob = C.ostart; seg = C.seg_sharp || any_between<PPL>(f_m, 0, pos - 1); }
             sharp[j] = (c0 + pos - s_glob >= 2) && seg;
         }
-        sharp_m.m[j] = __ballot(sharp[j]);
-        rts_m.m[j] = rec_m.m[j] & ~sharp_m.m[j];
+        sharp_m.set(j, __ballot(sharp[j]));
+        rts_m.set(j, rec_m.get(j) & ~sharp_m.get(j));
     }
     if (any(sharp_m)) C.status |= ST_SHARP_TURN;
     if (any(rts_m)) C.status |= ST_RTS_APPLIED;
@@ -314,7 +343,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             const bool in_run = active[j] && !av[j] && nr >= 0 && bit_at<PPL>(rts_m, nrc);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double dr = pick_shfl<PPL>(dcorr[0][c], dcorr[PPL - 1][c], nrc), pr = pick_shfl<PPL>(Pm[0][c], Pm[PPL - 1][c], nrc);
+                const double dr = pick_shfl<PPL>(GSF_SUBS(dcorr[j][c]), nrc), pr = pick_shfl<PPL>(GSF_SUBS(Pm[j][c]), nrc);
                 if (in_run) xo[j][c] = xl[j][c] + Pf[j][c] * fast_rcp(pr) * dr;
             }
         }
@@ -324,7 +353,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             if (r1 >= 0 && bit_at<PPL>(rts_m, r1)) {
                 double dr[3], ipr[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { dr[c] = pick_bcast<PPL>(dcorr[0][c], dcorr[PPL - 1][c], r1); ipr[c] = fast_rcp(pick_bcast<PPL>(Pm[0][c], Pm[PPL - 1][c], r1)); }
+                for (int c = 0; c < 3; ++c) { dr[c] = pick_bcast<PPL>(GSF_SUBS(dcorr[j][c]), r1); ipr[c] = fast_rcp(pick_bcast<PPL>(GSF_SUBS(Pm[j][c]), r1)); }
                 double acc = 0.0;                                         // sum of dt over (ostart, k]
                 for (int64_t k0 = (C.ostart / 64) * 64; k0 < c0; k0 += 64) {
                     const int64_t k = k0 + lane;
@@ -348,7 +377,7 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
         }
     }
 
-    // ---- output rows (stored at the bottom, after the prefetched rows have been waited for: see chunk_arrived)
+    // ---- output rows
     double orow[PPL][3];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) { orow[j][0] = C.p.x + xo[j][0]; orow[j][1] = C.p.y + xo[j][1]; orow[j][2] = C.p.z + xo[j][2]; }
@@ -361,14 +390,14 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
             C.ostart = c0 + s;
             C.seg_sharp = any_between<PPL>(f_m, s + 1, Lp);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) C.Pos[c] = pick_bcast<PPL>(Pf[0][c], Pf[PPL - 1][c], s);
+            for (int c = 0; c < 3; ++c) C.Pos[c] = pick_bcast<PPL>(GSF_SUBS(Pf[j][c]), s);
         } else {
             C.seg_sharp = C.seg_sharp || any_between<PPL>(f_m, 0, Lp);
         }
     }
     C.prev_avail = !open;
     {
-#define GSF_CARRY(dst, expr) { double e0, e1; { const int j = 0; e0 = (expr); } { const int j = PPL - 1; e1 = (expr); } dst = pick_bcast<PPL>(e0, e1, Lp); }
+#define GSF_CARRY(dst, expr) { dst = pick_bcast<PPL>(GSF_SUBS(expr), Lp); }
         double x0, x1, x2;
         GSF_CARRY(x0, xl[j][0]) GSF_CARRY(x1, xl[j][1]) GSF_CARRY(x2, xl[j][2])
         Quat nq; GSF_CARRY(nq.x, qi[j].x) GSF_CARRY(nq.y, qi[j].y) GSF_CARRY(nq.z, qi[j].z) GSF_CARRY(nq.w, qi[j].w)
@@ -381,7 +410,6 @@ __device__ __forceinline__ void process_chunk(const TrajPtrs& T, const EkfConfig
 #undef GSF_CARRY
         C.ok = bit_at<PPL>(ok_m, Lp);
     }
-    chunk_arrived(nx0); chunk_arrived(nx1);
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {                                       // PPL consecutive poses per lane
         if (active[j]) {

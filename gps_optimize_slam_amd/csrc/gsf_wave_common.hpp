@@ -28,6 +28,17 @@ __device__ __forceinline__ double dpp(double old, double v)
     const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// the same for a monoid whose identity is 0.0: on the full-row-mask stages (row_shr) bound_ctrl zero-fills the lanes without a
+// source, so no identity has to be materialised at all; the two row_bcast stages still need `old` = 0 for the masked-off rows
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp0(double v)
+{
+    if (ROW_MASK != 0xf) return dpp<CTRL, ROW_MASK>(0.0, v);
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ Quat dpp(const Quat& old, const Quat& v)
 {
@@ -51,7 +62,7 @@ __device__ __forceinline__ double shidx(double v, int src) { return __shfl(v, sr
 // sum over the wave: inclusive DPP scan, total read from lane 63 (wave-uniform result)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#define GSF_SUMSTAGE(CTRL, RM) { v += dpp<CTRL, RM>(0.0, v); }
+#define GSF_SUMSTAGE(CTRL, RM) { v += dpp0<CTRL, RM>(v); }
     GSF_SCAN_STAGES(GSF_SUMSTAGE)
 #undef GSF_SUMSTAGE
     return lane_bcast(v, 63);
@@ -107,11 +118,14 @@ __device__ __forceinline__ ChunkIn load_chunk(const double* __restrict__ tsb, co
 {
     const int64_t il = i < N ? i : N - 1;
     ChunkIn c;
-    c.t = tsb[il];
-    c.p = Vec3{ posb[il * 3], posb[il * 3 + 1], posb[il * 3 + 2] };
-    c.q = Quat{ quatb[il * 4], quatb[il * 4 + 1], quatb[il * 4 + 2], quatb[il * 4 + 3] };
-    c.z = Vec3{ gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2] };
-    c.v = valb[il];
+    // last use of every input row (the pipeline's fit pass has already run): streaming loads, so L2 keeps rows still to be fitted
+#define GSF_NT(p) __builtin_nontemporal_load(&(p))
+    c.t = GSF_NT(tsb[il]);
+    c.p = Vec3{ GSF_NT(posb[il * 3]), GSF_NT(posb[il * 3 + 1]), GSF_NT(posb[il * 3 + 2]) };
+    c.q = Quat{ GSF_NT(quatb[il * 4]), GSF_NT(quatb[il * 4 + 1]), GSF_NT(quatb[il * 4 + 2]), GSF_NT(quatb[il * 4 + 3]) };
+    c.z = Vec3{ GSF_NT(gpsb[il * 3]), GSF_NT(gpsb[il * 3 + 1]), GSF_NT(gpsb[il * 3 + 2]) };
+    c.v = GSF_NT(valb[il]);
+#undef GSF_NT
     return c;
 }
 
@@ -397,7 +411,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
             if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
             // mine (later) o other (earlier); lanes without a source see the identity map (1,0;0,1)
 #define GSF_MSTAGE(CTRL, RM) {                                                                                              \
-                const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp<CTRL, RM>(0.0, Bm), oC = dpp<CTRL, RM>(0.0, Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
+                const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp0<CTRL, RM>(Bm), oC = dpp0<CTRL, RM>(Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
                 const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
                 A = nA; Bm = nB; Cm = nC; Dm = nD; }
             GSF_SCAN_STAGES(GSF_MSTAGE)
@@ -410,16 +424,32 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         // ---- positions: prefix composition of affine maps x -> al x + be in chunk-local coordinates (x = p - p_carry)
         const double uu[3] = { u.x, u.y, u.z }, zl[3] = { z.x - cp.x, z.y - cp.y, z.z - cp.z };
         double xl[3], dcorr[3];
+        double al[3], be[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double kw = kg[c] * wgt;
-            double al = avail ? (1.0 - kw) : 1.0;
-            double be = avail ? ((1.0 - kw) * uu[c] + kw * zl[c]) : uu[c];
-#define GSF_ASTAGE(CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al), ob = dpp<CTRL, RM>(0.0, be); be = al * ob + be; al = al * oa; }
-            GSF_SCAN_STAGES(GSF_ASTAGE)
+            al[c] = avail ? (1.0 - kw) : 1.0;
+            be[c] = avail ? ((1.0 - kw) * uu[c] + kw * zl[c]) : uu[c];
+        }
+#define GSF_ASTAGE(c, CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al[c]), ob = dpp0<CTRL, RM>(be[c]); be[c] = al[c] * ob + be[c]; al[c] = al[c] * oa; }
+#define GSF_ASTAGE_X(CTRL, RM) GSF_ASTAGE(0, CTRL, RM)
+#define GSF_ASTAGE_Y(CTRL, RM) GSF_ASTAGE(1, CTRL, RM)
+#define GSF_ASTAGE_Z(CTRL, RM) GSF_ASTAGE(2, CTRL, RM)
+        // x and y share the gain in the default CONFIG, hence the multiplicative part: one joint scan of (al; be_x, be_y)
+#define GSF_ASTAGE_XY(CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al[0]), ob0 = dpp0<CTRL, RM>(be[0]), ob1 = dpp0<CTRL, RM>(be[1]); \
+                                  be[0] = al[0] * ob0 + be[0]; be[1] = al[0] * ob1 + be[1]; al[0] = al[0] * oa; }
+        if (same_axis[1] == 0) { GSF_SCAN_STAGES(GSF_ASTAGE_XY) }
+        else { GSF_SCAN_STAGES(GSF_ASTAGE_X) GSF_SCAN_STAGES(GSF_ASTAGE_Y) }
+        GSF_SCAN_STAGES(GSF_ASTAGE_Z)
+#undef GSF_ASTAGE_XY
+#undef GSF_ASTAGE_Z
+#undef GSF_ASTAGE_Y
+#undef GSF_ASTAGE_X
 #undef GSF_ASTAGE
-            xl[c] = be;                                                  // x_i (the carry is x = 0)
-            dcorr[c] = xl[c] - (prev_lane(0.0, be) + uu[c]);             // x_f[i] - x_p[i] (non-zero only where a fix was used)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xl[c] = be[c];                                               // x_i (the carry is x = 0)
+            dcorr[c] = xl[c] - (prev_lane(0.0, be[c]) + uu[c]);          // x_f[i] - x_p[i] (non-zero only where a fix was used)
         }
 
         // ---- per-outage RTS (ref :906-922, :777-803).  Inside an outage x_f = x_p and P_f = P_p, so the gain product
@@ -446,7 +476,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
                         const double tk = tsb[k];
                         const double tkp = prev_lane((k0 > 0) ? tsb[k0 - 1] : tk, tk);
                         double dsum = (k > c_ostart) ? fmax(1e-6, tk - tkp) : 0.0;
-#define GSF_SSTAGE(CTRL, RM) { dsum += dpp<CTRL, RM>(0.0, dsum); }
+#define GSF_SSTAGE(CTRL, RM) { dsum += dpp0<CTRL, RM>(dsum); }
                         GSF_SCAN_STAGES(GSF_SSTAGE)
 #undef GSF_SSTAGE
                         const double tot = lane_bcast(dsum, 63);
@@ -486,8 +516,11 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
         chunk_arrived(nxt);                                              // the next chunk's rows; then this chunk's stores
         if (active) {
-            pob[i * 3] = o0; pob[i * 3 + 1] = o1; pob[i * 3 + 2] = o2;
-            qob[i * 4] = qi.x; qob[i * 4 + 1] = qi.y; qob[i * 4 + 2] = qi.z; qob[i * 4 + 3] = qi.w;
+            // streaming stores: the fused rows are not read again (except by the rare carried-outage fix-up, which stays
+            // coherent through L2), so they should not wait in L2 for the end-of-kernel write-back
+            __builtin_nontemporal_store(o0, &pob[i * 3]); __builtin_nontemporal_store(o1, &pob[i * 3 + 1]); __builtin_nontemporal_store(o2, &pob[i * 3 + 2]);
+            __builtin_nontemporal_store(qi.x, &qob[i * 4]); __builtin_nontemporal_store(qi.y, &qob[i * 4 + 1]);
+            __builtin_nontemporal_store(qi.z, &qob[i * 4 + 2]); __builtin_nontemporal_store(qi.w, &qob[i * 4 + 3]);
         }
         GSF_STAMP(8 + (int)(c0 / 64));
     }

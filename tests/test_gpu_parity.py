@@ -230,8 +230,19 @@ def test_layouts_agree_and_shard_invariant(B):
     finally:
         B.context().set_option("ekf_variant", 0)
     np.testing.assert_array_equal(p9, p1); np.testing.assert_array_equal(q9, q1); np.testing.assert_array_equal(s9, s1)
+    # trajectory-major: bit for bit with the default build and with a pinned multi-pose build
     parts0 = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=0, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
     np.testing.assert_array_equal(np.concatenate([x[0] for x in parts0]), p0)
+    np.testing.assert_array_equal(np.concatenate([x[2] for x in parts0]), s0)
+    for ppl in (1, 5):
+        B.context().set_option("wave_ppl", ppl)
+        try:
+            full = B.ekf_fuse_batch(pj).host_traj_major()
+            parts0 = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=0, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
+        finally:
+            B.context().set_option("wave_ppl", 0)
+        np.testing.assert_array_equal(np.concatenate([x[0] for x in parts0]), full[0])
+        np.testing.assert_array_equal(np.concatenate([x[1] for x in parts0]), full[1])
     # shards generated independently (traj0 offset) == slices of the full batch, bit for bit
     parts = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=1, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
     np.testing.assert_array_equal(np.concatenate([x[0] for x in parts]), p1)
@@ -257,24 +268,26 @@ def test_pipeline_batch_vs_oracle(B, orc, layout):
         assert (st[b] & 0xff) == sto
 
 
-@pytest.mark.parametrize("variant", [8, 5])
-@pytest.mark.parametrize("N", [271, 1000, 64, 130])
-def test_experimental_kernel_variants_vs_oracle(B, orc, N, variant):
-    """The opt-in trajectory-major variants -- chunk-parallel block kernel (ekf_variant 8) and two-poses-per-lane wave kernel
-    (ekf_variant 5) -- against the oracle, incl. the generic bad-quaternion path."""
+@pytest.mark.parametrize("variant", [("ekf_variant", 8), ("ekf_variant", 5), ("wave_ppl", 1), ("wave_ppl", 2), ("wave_ppl", 3),
+                                     ("wave_ppl", 4), ("wave_ppl", 5)], ids=lambda v: f"{v[0]}{v[1]}")
+@pytest.mark.parametrize("N", [271, 1000, 64, 130, 321])
+def test_trajectory_major_kernel_variants_vs_oracle(B, orc, N, variant):
+    """Every trajectory-major build -- one to five poses per lane (wave_ppl 1..5; the automatic choice picks between 1 and 5 by
+    batch size), the chunk-parallel block kernel (ekf_variant 8) and the historical two-pose switch (ekf_variant 5) -- against
+    the oracle, incl. the generic bad-quaternion path."""
     import torch
     nb = 300
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=21)
     batch.quat[5, N // 2] = 0.0                      # one invalid quaternion -> generic (non-telescoped) path for track 5
     batch.quat[9, 0] = 0.0
     ctx = B.context()
-    ctx.set_option("ekf_variant", variant)
+    ctx.set_option(*variant)
     try:
         out = B.ekf_fuse_batch(batch)
         outp, R, t, s = B.fuse_pipeline_batch(batch)
         torch.cuda.synchronize()
     finally:
-        ctx.set_option("ekf_variant", 0)
+        ctx.set_option(variant[0], 0)
     h = batch.host_traj_major()
     p, q, st = out.host_traj_major()
     po, qo, sto = orc.fuse_batch(h["ts"], h["pos"], h["quat"], h["gps"], h["valid"], h["init_pos"], h["init_quat"])

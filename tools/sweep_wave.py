@@ -18,7 +18,7 @@ def timed(fn, reps):
 
 
 args = [x for x in sys.argv[1:] if not x.startswith("--")]
-variants = [0, 5, 8]
+variants = [0, 1, 2, 3, 4, 5]
 for x in sys.argv[1:]:
     if x.startswith("--variants="):
         variants = [int(v) for v in x.split("=")[1].split(",")]
@@ -29,11 +29,13 @@ for (nb, n) in shapes:
     bj = B.TrajectoryBatch.synthetic(nb, n, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
     oj = B.FusedPoses(bj.layout, nb, n, "cuda")
     for v in variants:
-        ctx.set_option("ekf_variant", v)
+        # 0 = default (automatic); 1..5 = forced poses per lane; 8 = chunk-parallel block kernel
+        ctx.set_option("ekf_variant", 8 if v == 8 else 0)
+        ctx.set_option("wave_ppl", v if 1 <= v <= 5 else 0)
         ms_e = timed(lambda: B.ekf_fuse_batch(bj, out=oj), reps)
         ms_p = timed(lambda: B.fuse_pipeline_batch(bj, out=oj), reps)
         print(json.dumps({"B": nb, "N": n, "variant": v, "ekf_us": round(ms_e * 1e3, 2), "pipeline_us": round(ms_p * 1e3, 2),
-                          "ekf_frac": round(nb * n * 145 / ms_e / 1e9 / 8000, 4), "pipeline_frac": round(nb * n * 145 / ms_p / 1e9 / 8000, 4)}), flush=True)
-    ctx.set_option("ekf_variant", 0)
+                          "ekf_frac": round(nb * n * 145 / (ms_e * 1e-3) / 8e12, 4), "pipeline_frac": round(nb * n * 145 / (ms_p * 1e-3) / 8e12, 4)}), flush=True)
+    ctx.set_option("ekf_variant", 0); ctx.set_option("wave_ppl", 0)
     del bj, oj
     torch.cuda.empty_cache()
