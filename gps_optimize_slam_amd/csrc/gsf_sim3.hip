@@ -53,7 +53,41 @@ __device__ __forceinline__ Moments wave_moments(const double* __restrict__ src, 
     return m;
 }
 
-// 64 point sets per block: reduce set-by-set with the whole wave, finish lane-parallel.
+// Shifted raw moments of one point set, as accumulated by the short-set path: n, sum a, sum b, sum |a|^2, sum a b^T with
+// a = src - src_shift, b = dst - dst_shift (the shift is a row of the set itself, so |a|, |b| <= the set's extent and
+// H = Sab - n ma mb^T loses nothing at UTM magnitudes).
+struct RawMoments { double n, Sa[3], Sb[3], Saa, Sab[9], as[3], bs[3]; };
+
+__device__ __forceinline__ int32_t finalize_raw(const RawMoments& m, double* R, double* t, double& s)
+{
+    if (!(m.n >= 3.0)) return SIM3_NONE;                                     // ref :430
+    const double rn = 1.0 / m.n;
+    const double ma[3] = { m.Sa[0] * rn, m.Sa[1] * rn, m.Sa[2] * rn }, mb[3] = { m.Sb[0] * rn, m.Sb[1] * rn, m.Sb[2] * rn };
+    double H[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] = m.Sab[k] - m.n * ma[k / 3] * mb[k % 3];
+    const double ssq = fmax(0.0, m.Saa - m.n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
+    const double sc[3] = { m.as[0] + ma[0], m.as[1] + ma[1], m.as[2] + ma[2] }, dc[3] = { m.bs[0] + mb[0], m.bs[1] + mb[1], m.bs[2] + mb[2] };
+    return umeyama_finalize(H, ssq, sc, dc, m.n, R, t, s);
+}
+
+// sum over the 16 lanes of a DPP row (inclusive scan, total in lane 15 of each row); bound_ctrl zero-fills: no identity moves
+__device__ __forceinline__ double row16_scan_sum(double v)
+{
+    v += dpp0<DPP_ROW_SHR1, 0xf>(v); v += dpp0<DPP_ROW_SHR2, 0xf>(v); v += dpp0<DPP_ROW_SHR4, 0xf>(v); v += dpp0<DPP_ROW_SHR8, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ int64_t shfl64(int64_t v, int src)
+{
+    const int lo = __shfl((int)v, src, 64), hi = __shfl((int)(v >> 32), src, 64);
+    return (int64_t)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// 64 point sets per block, SVD + closed form lane-parallel (lane k finishes set k).  The moments are reduced in one of two ways:
+//   * short sets (every set of the block <= 256 rows -- config C4's 50-pair windows): FOUR sets per pass, one per 16-lane DPP
+//     row; the 17 sums need only the four row_shr stages (no identity moves, no cross-row stages) and the rows of a set are
+//     read once (shifted raw moments).  ~120 wave-instructions per set instead of ~560.
+//   * long sets: the whole wave reduces one set after the other (two-pass centred moments).
 __global__ __launch_bounds__(64) void umeyama_batch_kernel(const double* __restrict__ src, const double* __restrict__ dst,
                                                            const uint8_t* __restrict__ mask, const int64_t* __restrict__ offsets,
                                                            int64_t B, double* __restrict__ R, double* __restrict__ t,
@@ -61,18 +95,85 @@ __global__ __launch_bounds__(64) void umeyama_batch_kernel(const double* __restr
 {
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
-    Moments mine; mine.n = 0.0;
     const int nsets = (int)((B - b0 < 64) ? (B - b0) : 64);
-    for (int k = 0; k < nsets; ++k) {
-        const int64_t i0 = offsets[b0 + k], i1 = offsets[b0 + k + 1];
-        Moments m = wave_moments(src, dst, mask, i0, i1, lane);
-        if (lane == k) mine = m;
-    }
-    if (lane >= nsets) return;
-    const int64_t b = b0 + lane;
+    // lane k holds the bounds of set k
+    const int64_t my_i0 = offsets[b0 + (lane < nsets ? lane : nsets - 1)], my_i1 = offsets[b0 + (lane < nsets ? lane : nsets - 1) + 1];
+    const int64_t my_len = lane < nsets ? my_i1 - my_i0 : 0;
+    const bool all_short = __ballot(my_len > 256) == 0ull;
     double Rb[9], tb[3], sb = NAN; int32_t st;
-    if (mine.n < 3.0) st = SIM3_NONE;                                        // ref :430
-    else st = umeyama_finalize(mine.H, mine.ssq, mine.sc, mine.dc, mine.n, Rb, tb, sb);
+    if (all_short) {
+        RawMoments mine;
+        mine.n = 0.0; mine.Saa = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mine.Sa[k] = mine.Sb[k] = mine.as[k] = mine.bs[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mine.Sab[k] = 0.0;
+        const int grp = lane >> 4, j0 = lane & 15, gbase = lane & 48;
+        for (int p = 0; 4 * p < nsets; ++p) {
+            const int k = 4 * p + grp;                                       // the set of my row group (may be >= nsets: empty)
+            const int ks = k < nsets ? k : nsets - 1;
+            const int64_t i0 = shfl64(my_i0, ks), i1 = k < nsets ? shfl64(my_i1, ks) : i0;
+            // ---- shift: the first usable row of the set (normally found in the first 16 rows)
+            double as0 = 0, as1 = 0, as2 = 0, bs0 = 0, bs1 = 0, bs2 = 0;
+            bool have = !(i0 < i1);
+            for (int64_t off = 0; __ballot(!have && i0 + off < i1) != 0ull; off += 16) {
+                const int64_t i = i0 + off + j0;
+                bool ok = i < i1 && !have;
+                double a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
+                if (ok) {
+                    ok = !mask || mask[i] != 0;
+                    a0 = src[i * 3]; a1 = src[i * 3 + 1]; a2 = src[i * 3 + 2]; c0 = dst[i * 3]; c1 = dst[i * 3 + 1]; c2 = dst[i * 3 + 2];
+                    ok = ok && (fabs(a0) < INFINITY) && (fabs(a1) < INFINITY) && (fabs(a2) < INFINITY) && (fabs(c0) < INFINITY) &&
+                         (fabs(c1) < INFINITY) && (fabs(c2) < INFINITY);
+                }
+                const u64 m = __ballot(ok);
+                const unsigned field = (unsigned)(m >> gbase) & 0xffffu;
+                const int srcl = gbase + (field ? __ffs((int)field) - 1 : 0);
+                const double f0 = shidx(a0, srcl), f1 = shidx(a1, srcl), f2 = shidx(a2, srcl), g0 = shidx(c0, srcl), g1 = shidx(c1, srcl), g2 = shidx(c2, srcl);
+                if (!have && field) { as0 = f0; as1 = f1; as2 = f2; bs0 = g0; bs1 = g1; bs2 = g2; have = true; }
+            }
+            // ---- shifted raw moments, 16 rows of each of the four sets per iteration
+            double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+            double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int64_t off = 0; __ballot(i0 + off < i1) != 0ull; off += 16) {
+                const int64_t i = i0 + off + j0;
+                if (i < i1 && (!mask || mask[i] != 0)) {
+                    const double a0 = src[i * 3] - as0, a1 = src[i * 3 + 1] - as1, a2 = src[i * 3 + 2] - as2;
+                    const double c0 = dst[i * 3] - bs0, c1 = dst[i * 3 + 1] - bs1, c2 = dst[i * 3 + 2] - bs2;
+                    cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += c0; Sb1 += c1; Sb2 += c2;
+                    Saa += a0 * a0 + a1 * a1 + a2 * a2;
+                    Sab[0] += a0 * c0; Sab[1] += a0 * c1; Sab[2] += a0 * c2;
+                    Sab[3] += a1 * c0; Sab[4] += a1 * c1; Sab[5] += a1 * c2;
+                    Sab[6] += a2 * c0; Sab[7] += a2 * c1; Sab[8] += a2 * c2;
+                }
+            }
+            // ---- row totals (lane 15 of each row), parked in the lane that finishes the set: lane 4p+g <- lane 16g+15
+            const int from = 16 * (lane & 3) + 15;
+            const bool take = (lane >> 2) == p;
+#define GSF_PARK(dst_, v_) { const double tot_ = shidx(row16_scan_sum(v_), from); dst_ = take ? tot_ : dst_; }
+            GSF_PARK(mine.n, cnt) GSF_PARK(mine.Sa[0], Sa0) GSF_PARK(mine.Sa[1], Sa1) GSF_PARK(mine.Sa[2], Sa2)
+            GSF_PARK(mine.Sb[0], Sb0) GSF_PARK(mine.Sb[1], Sb1) GSF_PARK(mine.Sb[2], Sb2) GSF_PARK(mine.Saa, Saa)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) GSF_PARK(mine.Sab[q], Sab[q])
+#undef GSF_PARK
+            // the shifts are row-group uniform: any lane of the group can hand them over
+            { const double v0 = shidx(as0, from), v1 = shidx(as1, from), v2 = shidx(as2, from), w0 = shidx(bs0, from), w1 = shidx(bs1, from), w2 = shidx(bs2, from);
+              if (take) { mine.as[0] = v0; mine.as[1] = v1; mine.as[2] = v2; mine.bs[0] = w0; mine.bs[1] = w1; mine.bs[2] = w2; } }
+        }
+        if (lane >= nsets) return;
+        st = finalize_raw(mine, Rb, tb, sb);
+    } else {
+        Moments mine; mine.n = 0.0;
+        for (int k = 0; k < nsets; ++k) {
+            const int64_t i0 = offsets[b0 + k], i1 = offsets[b0 + k + 1];
+            Moments m = wave_moments(src, dst, mask, i0, i1, lane);
+            if (lane == k) mine = m;
+        }
+        if (lane >= nsets) return;
+        if (mine.n < 3.0) st = SIM3_NONE;                                    // ref :430
+        else st = umeyama_finalize(mine.H, mine.ssq, mine.sc, mine.dc, mine.n, Rb, tb, sb);
+    }
+    const int64_t b = b0 + lane;
     if (st == SIM3_NONE) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rb[k] = NAN;
