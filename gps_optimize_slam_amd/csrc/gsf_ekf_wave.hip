@@ -102,6 +102,12 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     const int64_t* offsets)
 {
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
+    // short equal-length tracks CAN take the single-shot kernel (gsf_ekf_seg.hip: the whole trajectory in one pass, scans paid once
+    // per track) -- opt-in (gsf_set_option "seg_kernel" 1): it executes ~45 % fewer instructions per track but measured slower than
+    // the chunked kernel from ~500 tracks up (C2 K4 23.8 vs 17.6 us, 400k x 271 7.5 vs 3.5 ms: 240 registers and 28 KB of LDS per
+    // wave leave 5 waves per CU, and its 60 per-pose lane masks spill SGPRs); faster only below ~300 tracks (12 vs 15 us).
+    if (!offsets && ctx->wave_ppl == 0 && ctx->ekf_variant == 0 && ctx->seg_kernel == 1 && N <= 64 * SEG_MAX_P)
+        return launch_ekf_seg(ctx, pipeline, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status);
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
     // Poses per lane (gsf_set_option "wave_ppl": 0 = automatic, 1..5 forced).  Automatic is ONE pose per lane with a register

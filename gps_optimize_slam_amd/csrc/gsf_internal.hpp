@@ -17,6 +17,7 @@ struct gsf_ctx {
     size_t scratch_bytes;
     int ekf_variant;       // tuning knob (gsf_set_option "ekf_variant")
     int wave_ppl;          // poses per lane of the wave-per-trajectory kernels (gsf_set_option "wave_ppl"; 0 = automatic)
+    int seg_kernel;        // single-shot kernel for short tracks (gsf_set_option "seg_kernel"): 1 = whenever N fits, otherwise never (opt-in)
 };
 
 namespace gsf {
@@ -53,6 +54,13 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
                     const int64_t* offsets = nullptr);
+
+// single-shot kernel for short tracks: the whole trajectory in one wave pass, ceil(N/64) consecutive poses per lane
+// (gsf_ekf_seg.hip), equal-length batches with N <= 64 * SEG_MAX_P
+constexpr int SEG_MAX_P = 5;
+int launch_ekf_seg(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
+                   const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                   int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
 
 // wave-per-chunk / block-per-trajectory variant for small batches of short tracks (gsf_ekf_block.hip), N <= 1024
 int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,

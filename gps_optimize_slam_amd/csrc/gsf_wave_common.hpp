@@ -140,6 +140,56 @@ __device__ __forceinline__ void chunk_arrived(const ChunkIn& c)
     asm volatile("" :: "v"(c.t), "v"(c.p.x), "v"(c.p.y), "v"(c.p.z), "v"(c.q.x), "v"(c.q.y), "v"(c.q.z), "v"(c.q.w), "v"(c.z.x), "v"(c.z.y), "v"(c.z.z), "v"(c.v) : "memory");
 }
 
+// Second half of the fused fit: wave totals of the per-lane partial moments (shifted by as_ / bs_), Umeyama closed form, R/t/s
+// outputs, Sim3 of pose 0 (ref :439-451, :464-466).  Returns false -- after writing NaN rows and the status word -- when the fit
+// is None or pose 0's quaternion is invalid (wave-uniform).  sums = { n, Sa[3], Sb[3], Saa, Sab[9] } per lane.
+__device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64_t b, const int64_t base, const int64_t N, const int lane,
+                                                  const double* sums, const double* as_, const double* bs_, const Quat& qraw0,
+                                                  Vec3& p0, Quat& q0, int32_t& fit)
+{
+    double* __restrict__ pob = a.pos_out + base * 3;
+    double* __restrict__ qob = a.quat_out + base * 4;
+    const double n = wave_sum(sums[0]);
+    double Rb[9], tb[3], sb = NAN;
+    fit = SIM3_NONE;
+    if (n >= 3.0) {                                                       // ref :430
+        const double rn = 1.0 / n;
+        const double ma[3] = { wave_sum(sums[1]) * rn, wave_sum(sums[2]) * rn, wave_sum(sums[3]) * rn };
+        const double mb[3] = { wave_sum(sums[4]) * rn, wave_sum(sums[5]) * rn, wave_sum(sums[6]) * rn };
+        const double ssq = fmax(0.0, wave_sum(sums[7]) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
+        double H[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] = wave_sum(sums[8 + k]) - n * ma[k / 3] * mb[k % 3];
+        const double sc[3] = { as_[0] + ma[0], as_[1] + ma[1], as_[2] + ma[2] }, dc[3] = { bs_[0] + mb[0], bs_[1] + mb[1], bs_[2] + mb[2] };
+        GSF_STAMP(3);
+        fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);           // every lane redundantly (wave-uniform inputs)
+        GSF_STAMP(4);
+    }
+    Quat qn0; const bool q0ok = quat_unit(qraw0, qn0);
+    if (fit == SIM3_NONE || !q0ok) {                                      // wave-uniform
+        for (int64_t i = lane; i < N; i += 64) {
+            pob[i * 3] = NAN; pob[i * 3 + 1] = NAN; pob[i * 3 + 2] = NAN;
+            qob[i * 4] = NAN; qob[i * 4 + 1] = NAN; qob[i * 4 + 2] = NAN; qob[i * 4 + 3] = NAN;
+        }
+        if (lane == 0) {
+            for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
+            a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
+            if (GSF_STATUS_PTR(a)) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
+        }
+        return false;
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
+        a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
+    }
+    const double x = as_[0], y = as_[1], z = as_[2];                      // the source-side shift IS pose 0's position
+    p0 = Vec3{ sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + tb[0], sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + tb[1],
+               sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + tb[2] };       // ref :464
+    q0 = quat_mul(quat_from_matrix(Rb), qn0);                            // ref :465-466
+    GSF_STAMP(5);
+    return true;
+}
+
 // Initial pose of trajectory b: either the caller's Sim3-aligned pose 0, or (PIPELINE) the Umeyama fit on the rows with valid
 // finite GNSS + Sim3 of pose 0.  Returns false (after writing NaN outputs / status) when the fit is None or pose 0's quaternion
 // is invalid -- wave-uniformly.
@@ -151,8 +201,6 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
     const double* __restrict__ quatb = a.quat + base * 4;
     const double* __restrict__ gpsb = a.gps + base * 3;
     const uint8_t* __restrict__ valb = a.valid + base;
-    double* __restrict__ pob = a.pos_out + base * 3;
-    double* __restrict__ qob = a.quat_out + base * 4;
     // ------------------------------------------------------------------ initial pose
     Vec3 p0; Quat q0;
     int32_t fit = 0;
@@ -215,44 +263,9 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
             }
         }
         GSF_STAMP(2);
-        const double n = wave_sum(cnt);
-        double Rb[9], tb[3], sb = NAN;
-        fit = SIM3_NONE;
-        if (n >= 3.0) {                                                   // ref :430
-            const double rn = 1.0 / n;
-            const double ma[3] = { wave_sum(Sa0) * rn, wave_sum(Sa1) * rn, wave_sum(Sa2) * rn };
-            const double mb[3] = { wave_sum(Sb0) * rn, wave_sum(Sb1) * rn, wave_sum(Sb2) * rn };
-            double H[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) H[k] = wave_sum(Sab[k]) - n * ma[k / 3] * mb[k % 3];
-            const double ssq = fmax(0.0, wave_sum(Saa) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
-            const double sc[3] = { as0 + ma[0], as1 + ma[1], as2 + ma[2] }, dc[3] = { bs0 + mb[0], bs1 + mb[1], bs2 + mb[2] };
-            GSF_STAMP(3);
-            fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);       // every lane redundantly (wave-uniform inputs)
-            GSF_STAMP(4);
-        }
-        Quat qn0; const bool q0ok = quat_unit(qraw0, qn0);
-        if (fit == SIM3_NONE || !q0ok) {                                  // wave-uniform
-            for (int64_t i = lane; i < N; i += 64) {
-                pob[i * 3] = NAN; pob[i * 3 + 1] = NAN; pob[i * 3 + 2] = NAN;
-                qob[i * 4] = NAN; qob[i * 4 + 1] = NAN; qob[i * 4 + 2] = NAN; qob[i * 4 + 3] = NAN;
-            }
-            if (lane == 0) {
-                for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
-                a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
-                if (GSF_STATUS_PTR(a)) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
-            }
-            return false;
-        }
-        if (lane == 0) {
-            for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
-            a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
-        }
-        const double x = as0, y = as1, z = as2;
-        p0 = Vec3{ sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + tb[0], sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + tb[1],
-                   sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + tb[2] };   // ref :464
-        q0 = quat_mul(quat_from_matrix(Rb), qn0);                        // ref :465-466
-        GSF_STAMP(5);
+        const double sums[17] = { cnt, Sa0, Sa1, Sa2, Sb0, Sb1, Sb2, Saa, Sab[0], Sab[1], Sab[2], Sab[3], Sab[4], Sab[5], Sab[6], Sab[7], Sab[8] };
+        const double as_[3] = { as0, as1, as2 }, bs_[3] = { bs0, bs1, bs2 };
+        if (!fit_from_partials(a, b, base, N, lane, sums, as_, bs_, qraw0, p0, q0, fit)) return false;
     } else {
         p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
         q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };

@@ -269,12 +269,12 @@ def test_pipeline_batch_vs_oracle(B, orc, layout):
 
 
 @pytest.mark.parametrize("variant", [("ekf_variant", 8), ("ekf_variant", 5), ("wave_ppl", 1), ("wave_ppl", 2), ("wave_ppl", 3),
-                                     ("wave_ppl", 4), ("wave_ppl", 5)], ids=lambda v: f"{v[0]}{v[1]}")
+                                     ("wave_ppl", 4), ("wave_ppl", 5), ("seg_kernel", 1)], ids=lambda v: f"{v[0]}{v[1]}")
 @pytest.mark.parametrize("N", [271, 1000, 64, 130, 321])
 def test_trajectory_major_kernel_variants_vs_oracle(B, orc, N, variant):
-    """Every trajectory-major build -- one to five poses per lane (wave_ppl 1..5; the automatic choice picks between 1 and 5 by
-    batch size), the chunk-parallel block kernel (ekf_variant 8) and the historical two-pose switch (ekf_variant 5) -- against
-    the oracle, incl. the generic bad-quaternion path."""
+    """Every trajectory-major build -- one to five poses per lane (wave_ppl 1..5; automatic = 1), the chunk-parallel block kernel
+    (ekf_variant 8), the historical two-pose switch (ekf_variant 5) and the single-shot short-track kernel (seg_kernel 1, N <= 320)
+    -- against the oracle, incl. the generic bad-quaternion path."""
     import torch
     nb = 300
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=21)
