@@ -282,17 +282,10 @@ GSF_HD TmConsts tm_consts()
     return c;
 }
 
-// Sum_{j=1..6} c_j * {sin,cos}(2j x) * {cosh,sinh}(2j y) via angle-addition recurrences:
-// one sincos + one exp pair instead of 24 transcendental calls.
-GSF_HD void tm_series(const double* c, double x, double y, double& s_sin_cosh, double& s_cos_sinh)
+// Sum_{j=1..6} c_j * {sin,cos}(2j x) * {cosh,sinh}(2j y) via angle-addition recurrences from the j = 1 values
+// (s2, c2) = (sin 2x, cos 2x) and (sh2, ch2) = (sinh 2y, cosh 2y): no transcendental call in here.
+GSF_HD void tm_series(const double* c, double s2, double c2, double sh2, double ch2, double& s_sin_cosh, double& s_cos_sinh)
 {
-    double s2 = sin(2.0 * x), c2 = cos(2.0 * x);
-    double ey = exp(2.0 * y), eyi = 1.0 / ey;
-    double ch2 = 0.5 * (ey + eyi), sh2 = 0.5 * (ey - eyi);
-    if (fabs(y) < 0.05) {             // sinh by series near 0 (eta is < 0.1 inside a UTM zone): no cancellation
-        double z = 2.0 * y, z2 = z * z;
-        sh2 = z * (1.0 + z2 / 6.0 * (1.0 + z2 / 20.0 * (1.0 + z2 / 42.0 * (1.0 + z2 / 72.0 * (1.0 + z2 / 110.0)))));
-    }
     double sj = s2, cj = c2, chj = ch2, shj = sh2;
     double a = 0.0, b = 0.0;
 #pragma unroll
@@ -306,23 +299,72 @@ GSF_HD void tm_series(const double* c, double x, double y, double& s_sin_cosh, d
     s_sin_cosh = a; s_cos_sinh = b;
 }
 
-// forward: degrees -> metres.  lon0_deg = 6*zone-183; fn = 0 or 1e7
+GSF_HD void gsf_sincos(double x, double& s, double& c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    ::sincos(x, &s, &c);
+#else
+    s = sin(x); c = cos(x);
+#endif
+}
+
+// sigma(tau) = sinh(e atanh(e tau / sqrt(1 + tau^2))) = sinh(e atanh(e sin phi)) (Karney 2011 eq. 8-9).  |e sin phi| <= 0.082,
+// so both functions are short odd series (remainders < 1e-17 relative) instead of two libm calls.
+GSF_HD double tm_sigma(double e, double sin_phi)
+{
+    const double z = e * sin_phi, z2 = z * z;
+    const double ath = z * (1.0 + z2 * (1.0 / 3 + z2 * (1.0 / 5 + z2 * (1.0 / 7 + z2 * (1.0 / 9 + z2 * (1.0 / 11 + z2 * (1.0 / 13 + z2 * (1.0 / 15))))))));
+    const double y = e * ath, y2 = y * y;
+    return y * (1.0 + y2 * (1.0 / 6 + y2 * (1.0 / 120 + y2 * (1.0 / 5040))));
+}
+
+// asinh for the small arguments of a UTM zone (|w| = |sinh eta'| <= sin 3 deg = 0.052 on the equator): alternating series to
+// w^18 below 1/8 (remainder < 4e-17), libm beyond.
+GSF_HD double asinh_small(double w)
+{
+    if (!(fabs(w) < 0.125)) return asinh(w);
+    const double w2 = w * w;
+    return w * (1.0 + w2 * (-1.0 / 6 + w2 * (3.0 / 40 + w2 * (-15.0 / 336 + w2 * (105.0 / 3456 + w2 * (-945.0 / 42240 + w2 * (10395.0 / 599040 +
+               w2 * (-135135.0 / 9676800 + w2 * (2027025.0 / 175472640)))))))));
+}
+
+// forward: degrees -> metres.  lon0_deg = 6*zone-183; fn = 0 or 1e7.  Karney's exact-tau form of the Krueger series; the only
+// libm-class calls left are sincos(phi), sincos(lambda) and atan2:
+//   sin/cos(2 xi') come from (tau', cos lambda) / hypot, and with w = sin(lambda) / hypot = sinh(eta') exactly,
+//   sinh(2 eta') = 2 w sqrt(1 + w^2), cosh(2 eta') = 1 + 2 w^2 -- no exp, no second sincos.
 GSF_HD void utm_forward_point(const TmConsts& c, double lat_deg, double lon_deg, double lon0_deg, double fn,
                               double& easting, double& northing)
 {
     const double d2r = 0.017453292519943295769;
-    double phi = lat_deg * d2r, lam = lon_deg * d2r - lon0_deg * d2r;
-    double tau = tan(phi);
-    double t1 = sqrt(1.0 + tau * tau);
-    double sig = sinh(c.e * atanh(c.e * tau / t1));
-    double taup = tau * sqrt(1.0 + sig * sig) - sig * t1;
-    double cl = cos(lam), sl = sin(lam);
-    double xip = atan2(taup, cl);
-    double etap = asinh(sl / sqrt(taup * taup + cl * cl));
+    const double phi = lat_deg * d2r, lam = lon_deg * d2r - lon0_deg * d2r;
+    double sp, cp; gsf_sincos(phi, sp, cp);
+    const double t1 = 1.0 / cp, tau = sp * t1;                // tan(phi), sqrt(1 + tan^2)   (|phi| <= pi/2: cp >= 0)
+    const double sig = tm_sigma(c.e, sp);
+    const double taup = tau * sqrt(1.0 + sig * sig) - sig * t1;
+    double sl, cl; gsf_sincos(lam, sl, cl);
+    const double ih = 1.0 / sqrt(taup * taup + cl * cl);
+    const double xip = atan2(taup, cl);
+    const double w = sl * ih;                                  // sinh(eta')
+    const double etap = asinh_small(w);
+    const double s1 = taup * ih, c1 = cl * ih;                 // sin(xi'), cos(xi')
+    const double ch1 = sqrt(1.0 + w * w);
     double a, b;
-    tm_series(c.alpha, xip, etap, a, b);
+    tm_series(c.alpha, 2.0 * s1 * c1, (c1 - s1) * (c1 + s1), 2.0 * w * ch1, 1.0 + 2.0 * w * w, a, b);
     easting = 500000.0 + c.k0A * (etap + b);
     northing = fn + c.k0A * (xip + a);
+}
+
+// sinh / cosh of a small argument by series (|z| < 1/2: remainders < 1e-17), exp beyond
+GSF_HD void sinh_cosh_small(double z, double& sh, double& ch)
+{
+    if (fabs(z) < 0.5) {
+        const double z2 = z * z;
+        sh = z * (1.0 + z2 / 6.0 * (1.0 + z2 / 20.0 * (1.0 + z2 / 42.0 * (1.0 + z2 / 72.0 * (1.0 + z2 / 110.0 * (1.0 + z2 / 156.0 * (1.0 + z2 / 210.0)))))));
+        ch = 1.0 + z2 / 2.0 * (1.0 + z2 / 12.0 * (1.0 + z2 / 30.0 * (1.0 + z2 / 56.0 * (1.0 + z2 / 90.0 * (1.0 + z2 / 132.0 * (1.0 + z2 / 182.0 * (1.0 + z2 / 240.0)))))));
+    } else {
+        const double ez = exp(z), ezi = 1.0 / ez;
+        sh = 0.5 * (ez - ezi); ch = 0.5 * (ez + ezi);
+    }
 }
 
 // inverse: metres -> degrees
@@ -331,17 +373,21 @@ GSF_HD void utm_inverse_point(const TmConsts& c, double easting, double northing
 {
     const double r2d = 57.295779513082320877;
     double xi = (northing - fn) / c.k0A, eta = (easting - 500000.0) / c.k0A;
+    double s2, c2, sh2, ch2;
+    gsf_sincos(2.0 * xi, s2, c2);
+    sinh_cosh_small(2.0 * eta, sh2, ch2);
     double a, b;
-    tm_series(c.beta, xi, eta, a, b);
+    tm_series(c.beta, s2, c2, sh2, ch2, a, b);
     double xip = xi - a, etap = eta - b;
-    double sh = sinh(etap), cx = cos(xip);
-    double taup = sin(xip) / sqrt(sh * sh + cx * cx);
+    double sh, chd; sinh_cosh_small(etap, sh, chd);
+    double sx, cx; gsf_sincos(xip, sx, cx);
+    double taup = sx / sqrt(sh * sh + cx * cx);
     double lam = atan2(sh, cx);
     double e2m = 1.0 - c.e * c.e;
     double tau = taup / e2m;
     for (int it = 0; it < 6; ++it) {           // Newton on tau'(tau) (Karney 2011 eqs 19-21); converges in 2-3
         double t1 = sqrt(1.0 + tau * tau);
-        double sig = sinh(c.e * atanh(c.e * tau / t1));
+        double sig = tm_sigma(c.e, tau / t1);
         double tpi = tau * sqrt(1.0 + sig * sig) - sig * t1;
         double dtau = (taup - tpi) / sqrt(1.0 + tpi * tpi) * (1.0 + e2m * tau * tau) / (e2m * t1);
         tau += dtau;
