@@ -12,7 +12,9 @@ Workloads (BASELINE.json configs):
   c2 (default, configs[1]) 1k synthetic KITTI-04-length (271-pose) trajectories per GPU
   c3 (configs[2])          100k synthetic 1k-pose trajectories per GPU (HBM-bound regime)
 N > 1: one process per GPU (torch.distributed / RCCL), trajectories sharded by contiguous id blocks (weak scaling: the
-per-GPU batch is fixed), every step ends with the RCCL all-gather of the fused poses the north star names.
+per-GPU batch is fixed, no collective on the data path); the timed region is the K steps plus the ONE RCCL all-gather that
+collects the fused poses (north star / SURVEY 8e).  The collect is also reported on its own ("collect": all-gather time,
+received GB/s per rank, compute-only rate, and the rate when every step's result is gathered everywhere).
 Prints ONE JSON line on rank 0 (contract in the round brief): metric/value/unit + roofline + cpu_baseline.
 """
 import argparse
@@ -98,6 +100,7 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible -- the fusion path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
+    local = local % torch.cuda.device_count()   # one rank per GPU on a full node; ranks share a GPU only in a gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
@@ -135,38 +138,32 @@ def main():
         gather_bufs = (torch.empty((world * out.pos.shape[0],) + tuple(out.pos.shape[1:]), dtype=torch.float64, device=dev),
                        torch.empty((world * out.quat.shape[0],) + tuple(out.quat.shape[1:]), dtype=torch.float64, device=dev))
 
-    def step():
-        launch()
-        if world > 1:                           # the collect step: fused poses of every shard to every GPU (RCCL over xGMI)
-            D._gather(out.pos, world, gather_bufs[0])
-            D._gather(out.quat, world, gather_bufs[1])
+    def collect():                              # the job's ONE collect: fused poses of every shard to every GPU (RCCL over xGMI)
+        D._gather(out.pos, world, gather_bufs[0])
+        D._gather(out.quat, world, gather_bufs[1])
 
     for _ in range(warmup):
-        step()
+        launch()
+    if world > 1:
+        collect()                               # communicator set-up stays outside the timed region
     D.barrier(dev); torch.cuda.synchronize()
+    # Timed region = the K fusion steps of this rank's shard (no collective on the data path: trajectories are independent) +
+    # the single all-gather that collects the fused poses (north star / SURVEY 8e), bracketed by barrier + synchronize.
     # HIP events on torch's current stream == the stream the kernels are launched on (B.context()).  One pair around the K
-    # launches: at C2 a launch is ~30 us, so per-launch event pairs would make the loop host-bound and pad the gaps.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # launches: at C2 a launch is ~25 us, so per-launch event pairs would make the loop host-bound and pad the gaps.
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
     ev0.record()
     for k in range(steps):
         launch()
-        if world > 1:
-            D._gather(out.pos, world, gather_bufs[0])
-            D._gather(out.quat, world, gather_bufs[1])
     ev1.record()
+    if world > 1:
+        collect()
+    ev2.record()
     torch.cuda.synchronize(); D.barrier(dev)
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
-    span_ms = ev0.elapsed_time(ev1)
-    if world == 1:
-        kern_ms = span_ms / steps               # back-to-back launches of the one kernel: span / K = average launch duration
-    else:                                       # with the collective in the loop, time the kernel alone in a second pass
-        torch.cuda.synchronize()
-        ev0.record()
-        for k in range(steps):
-            launch()
-        ev1.record(); torch.cuda.synchronize()
-        kern_ms = ev0.elapsed_time(ev1) / steps
+    kern_ms = ev0.elapsed_time(ev1) / steps     # back-to-back launches of the one kernel: span / K = average launch duration
+    collect_ms = ev1.elapsed_time(ev2) if world > 1 else 0.0
     poses_per_step = world * Bn * N
     value = poses_per_step * steps / elapsed
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
@@ -182,10 +179,26 @@ def main():
         "metric": "fused poses/sec (whole node)", "value": value, "unit": "fused poses/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)" if layout_name == "traj" else "time-major SoA (lane-per-trajectory)", "step": args.kernel,
-                   "parallelism": f"trajectory-sharded x{world}" + (", RCCL all-gather of fused poses per step" if world > 1 else "")},
+                   "parallelism": f"trajectory-sharded x{world}" + (", one RCCL all-gather of the fused poses after the K steps (inside the timed region)" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
+    if world > 1:
+        # the collect, reported on its own (compute-only and compute+gather separately): bytes each rank RECEIVES from the
+        # others over xGMI / time of the single all-gather, and -- as a second, short leg -- the rate when EVERY step's result is
+        # collected everywhere (all-gather issued after each step: link-bound by construction, 56 B/pose over xGMI against
+        # 145 B/pose over HBM)
+        recv = (world - 1) * Bn * N * 56
+        k2 = max(1, min(steps, 20))
+        D.barrier(dev); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(k2):
+            launch(); collect()
+        torch.cuda.synchronize(); D.barrier(dev)
+        el2 = D.max_over_ranks(time.perf_counter() - t1, dev)
+        result["collect"] = {"allgather_ms": collect_ms, "recv_bytes_per_rank": recv, "recv_GBps_per_rank": recv / (collect_ms * 1e-3) / 1e9 if collect_ms > 0 else None,
+                             "compute_only_poses_per_s": world * Bn * N / (kern_ms * 1e-3),
+                             "collect_every_step": {"steps": k2, "ms_per_step": el2 / k2 * 1e3, "poses_per_s": poses_per_step * k2 / el2}}
     # ---- accuracy gate on this run: ATE RMSE of the GPU result vs the CPU oracle on a sample of the timed batch
     if rank == 0:
         import numpy as np
