@@ -647,3 +647,63 @@ def test_capi_error_paths(B):
         _lib.check(L.gsf_set_option(h, b"no_such_option", 1))
     # B == 0 is a no-op success on every batched entry
     assert L.gsf_utm_forward_batch_dev(h, None, None, offs.data_ptr(), offs.data_ptr(), offs.data_ptr(), 0, None, None) == 0
+
+
+def _random_outage_batch(nb, N, seed):
+    """Host-made stress batch: several outages per track with lengths from 1 pose to half the track, fixes that are NaN with the
+    mask still set (demoted by the gate, Q10), yaw bursts inside outages (sharp-turn recoveries), outages at both ends,
+    jittered and occasionally repeated stamps."""
+    rng = np.random.default_rng(seed)
+    dt = 0.1 + rng.uniform(-0.004, 0.004, size=(nb, N)); dt[:, 0] = 0.0
+    dt[rng.random((nb, N)) < 0.01] = 0.0                                  # repeated stamps -> the dt clamp (Q9)
+    ts = np.cumsum(dt, axis=1)
+    head = np.cumsum(rng.normal(0, 0.01, size=(nb, N)), axis=1)
+    valid = np.ones((nb, N), dtype=np.uint8)
+    yaw_extra = np.zeros((nb, N))
+    for b in range(nb):
+        for _ in range(rng.integers(0, 5)):
+            L = int(rng.choice([1, 2, 3, 7, 40, 64, 65, 130, N // 2]))
+            s = int(rng.integers(0, max(1, N - L)))
+            valid[b, s:s + L] = 0
+            if L >= 3 and rng.random() < 0.5:                             # a turn faster than the 45 deg/s gate, inside the outage
+                k = s + 1 + int(rng.integers(0, L - 2))
+                yaw_extra[b, k:] += rng.choice([-1.0, 1.0]) * rng.uniform(0.3, 1.2)
+        if rng.random() < 0.2: valid[b, :int(rng.integers(1, 90))] = 0
+        if rng.random() < 0.2: valid[b, N - int(rng.integers(1, 90)):] = 0
+    step = 1.4 * np.stack([np.cos(head), np.sin(head), 0.01 * np.ones_like(head)], -1) * (dt[..., None] / 0.1)
+    pos = np.cumsum(step, axis=1) + rng.normal(0, 0.01, size=(nb, N, 3))
+    yaw = head + yaw_extra                                                # rotation about z: what the reference's yaw gate sees
+    quat = np.stack([np.zeros_like(yaw), np.zeros_like(yaw), np.sin(yaw / 2), np.cos(yaw / 2)], -1) * rng.uniform(0.5, 2.0, size=(nb, N, 1))
+    gps = pos * 1.03 + np.array([4.5e5, 5.4e6, 110.0]) + rng.normal(0, 0.4, size=(nb, N, 3))
+    gps[valid == 0] = np.nan
+    nanfix = (rng.random((nb, N)) < 0.01) & (valid == 1)
+    gps[nanfix, rng.integers(0, 3)] = np.nan                              # NaN fix, mask still set
+    init_pos = gps[:, 0].copy(); init_pos[np.isnan(init_pos)] = 0.0
+    init_pos += np.array([4.5e5, 5.4e6, 110.0]) * np.isnan(gps[:, 0]).any(axis=1, keepdims=True)
+    init_quat = quat[:, 0] / np.linalg.norm(quat[:, 0], axis=1, keepdims=True)
+    return ts, pos, quat, gps, valid, init_pos, init_quat
+
+
+@pytest.mark.parametrize("N", [300, 777])
+def test_random_outage_patterns_every_kernel_vs_oracle(B, orc, N):
+    """Outage structure stress: every K4 build (both layouts and all opt-in variants) against the dense oracle on tracks with up to
+    four outages of 1..N/2 poses, NaN fixes, sharp-turn recoveries, outages at both ends -- positions inside the gate, status bits
+    and therefore every start / recovery / sharp-turn / RTS decision exact."""
+    nb = 192
+    ts, pos, quat, gps, valid, ip, iq = _random_outage_batch(nb, N, seed=100 + N)
+    po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
+    for bit in (1, 2, 4, 8):                          # outage, RTS, sharp-turn recovery, ended-in-outage all occur in the batch
+        assert (sto & bit).any(), bit
+    ctx = B.context()
+    builds = [("default", None, 0), ("time-major lane kernel", None, 1), ("wave_ppl", 2, 0), ("wave_ppl", 5, 0), ("ekf_variant", 8, 0), ("seg_kernel", 1, 0)]
+    for key, val, layout in builds:
+        batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
+        if val is not None:
+            ctx.set_option(key, val)
+        try:
+            p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
+        finally:
+            if val is not None:
+                ctx.set_option(key, 0)
+        np.testing.assert_array_equal(st, sto, err_msg=f"{key} {val}")
+        assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL, (key, val, np.abs(p - po).max())
