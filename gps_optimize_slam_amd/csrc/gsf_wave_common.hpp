@@ -67,6 +67,61 @@ __device__ __forceinline__ double wave_sum(double v)
 #undef GSF_SUMSTAGE
     return lane_bcast(v, 63);
 }
+// ---- SIXTEEN wave sums at once (the moments of a point set): a "transposing" butterfly.  Each exchange stage halves the number
+// of values a lane carries -- lane pairs swap complementary halves and add -- so the sixteen values cost 8+4+2+1 exchanges inside
+// a 16-lane row (instead of 16 x 4 scan stages), two more adds across the four rows, and one v_readlane pair per total.
+// ~150 instructions instead of ~420 for sixteen wave_sum() calls.  Inputs are scalars and the result is a by-value struct written
+// with constant indices on purpose (see the note on pick helpers in gsf_wave_chunk.hpp: no select between array elements here).
+struct Sums16 { double v[16]; };
+// partner exchange inside a quad (xor 1 / xor 2): DPP quad_perm, every lane has a source
+template <int QP> __device__ __forceinline__ double dpp_quad(double v)
+{
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)x, QP, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), QP, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// partner at distance D = 4 or 8 inside a 16-lane row (lane ^ D): row_shl:D into the banks whose bit is clear, row_shr:D into the others
+template <int D> __device__ __forceinline__ double dpp_row_xor(double v)
+{
+    constexpr int SHL = 0x100 + D, SHR = 0x110 + D;
+    constexpr int LOW_BANKS = (D == 4) ? 0x5 : 0x3, HIGH_BANKS = (D == 4) ? 0xa : 0xc;
+    const long long x = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)x, SHL, 0xf, LOW_BANKS, false);
+    lo = __builtin_amdgcn_update_dpp(lo, (int)x, SHR, 0xf, HIGH_BANKS, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), SHL, 0xf, LOW_BANKS, false);
+    hi = __builtin_amdgcn_update_dpp(hi, (int)(x >> 32), SHR, 0xf, HIGH_BANKS, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ Sums16 wave_sum16(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7,
+                                            double a8, double a9, double a10, double a11, double a12, double a13, double a14, double a15, int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+    // keep the half selected by my bit, hand the other half to the partner, add what the partner hands over
+#define GSF_BFLY(bit, lo_, hi_, XCHG) ((bit ? hi_ : lo_) + XCHG(bit ? lo_ : hi_))
+    // stage 1 (lane ^ 1): 16 -> 8 values;  b0 = 0 keeps indices 0..7, b0 = 1 keeps 8..15
+    const double w0 = GSF_BFLY(b0, a0, a8, dpp_quad<0xB1>), w1 = GSF_BFLY(b0, a1, a9, dpp_quad<0xB1>), w2 = GSF_BFLY(b0, a2, a10, dpp_quad<0xB1>),
+                 w3 = GSF_BFLY(b0, a3, a11, dpp_quad<0xB1>), w4 = GSF_BFLY(b0, a4, a12, dpp_quad<0xB1>), w5 = GSF_BFLY(b0, a5, a13, dpp_quad<0xB1>),
+                 w6 = GSF_BFLY(b0, a6, a14, dpp_quad<0xB1>), w7 = GSF_BFLY(b0, a7, a15, dpp_quad<0xB1>);
+    // stage 2 (lane ^ 2): 8 -> 4
+    const double x0 = GSF_BFLY(b1, w0, w4, dpp_quad<0x4E>), x1 = GSF_BFLY(b1, w1, w5, dpp_quad<0x4E>), x2 = GSF_BFLY(b1, w2, w6, dpp_quad<0x4E>),
+                 x3 = GSF_BFLY(b1, w3, w7, dpp_quad<0x4E>);
+    // stage 3 (lane ^ 4): 4 -> 2;  stage 4 (lane ^ 8): 2 -> 1
+    const double y0 = GSF_BFLY(b2, x0, x2, dpp_row_xor<4>), y1 = GSF_BFLY(b2, x1, x3, dpp_row_xor<4>);
+    double z = GSF_BFLY(b3, y0, y1, dpp_row_xor<8>);
+#undef GSF_BFLY
+    // lane l now holds the sum over its 16-lane row of value index 8 b0 + 4 b1 + 2 b2 + b3; add the four rows
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    Sums16 r;
+    // index j lives in the lane whose low four bits are the bit reversal of j
+#define GSF_OUT(j) r.v[j] = lane_bcast(z, ((j >> 3) & 1) | (((j >> 2) & 1) << 1) | (((j >> 1) & 1) << 2) | ((j & 1) << 3));
+    GSF_OUT(0) GSF_OUT(1) GSF_OUT(2) GSF_OUT(3) GSF_OUT(4) GSF_OUT(5) GSF_OUT(6) GSF_OUT(7)
+    GSF_OUT(8) GSF_OUT(9) GSF_OUT(10) GSF_OUT(11) GSF_OUT(12) GSF_OUT(13) GSF_OUT(14) GSF_OUT(15)
+#undef GSF_OUT
+    return r;
+}
+
 // bits lo..hi (inclusive) of a 64-bit mask; empty if lo > hi
 __device__ __forceinline__ u64 bits(int lo, int hi)
 {
@@ -153,13 +208,15 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
     double Rb[9], tb[3], sb = NAN;
     fit = SIM3_NONE;
     if (n >= 3.0) {                                                       // ref :430
+        const Sums16 S = wave_sum16(sums[1], sums[2], sums[3], sums[4], sums[5], sums[6], sums[7], sums[8], sums[9], sums[10], sums[11],
+                                    sums[12], sums[13], sums[14], sums[15], sums[16], lane);
         const double rn = 1.0 / n;
-        const double ma[3] = { wave_sum(sums[1]) * rn, wave_sum(sums[2]) * rn, wave_sum(sums[3]) * rn };
-        const double mb[3] = { wave_sum(sums[4]) * rn, wave_sum(sums[5]) * rn, wave_sum(sums[6]) * rn };
-        const double ssq = fmax(0.0, wave_sum(sums[7]) - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
+        const double ma[3] = { S.v[0] * rn, S.v[1] * rn, S.v[2] * rn };
+        const double mb[3] = { S.v[3] * rn, S.v[4] * rn, S.v[5] * rn };
+        const double ssq = fmax(0.0, S.v[6] - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));
         double H[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) H[k] = wave_sum(sums[8 + k]) - n * ma[k / 3] * mb[k % 3];
+        for (int k = 0; k < 9; ++k) H[k] = S.v[7 + k] - n * ma[k / 3] * mb[k % 3];
         const double sc[3] = { as_[0] + ma[0], as_[1] + ma[1], as_[2] + ma[2] }, dc[3] = { bs_[0] + mb[0], bs_[1] + mb[1], bs_[2] + mb[2] };
         GSF_STAMP(3);
         fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);           // every lane redundantly (wave-uniform inputs)
