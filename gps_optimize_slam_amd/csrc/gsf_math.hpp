@@ -405,8 +405,9 @@ struct EnuFrame { double x0, y0, z0, sl, cl, sp, cp; };      // ECEF of the orig
 GSF_HD void geodetic_to_ecef(double lat_deg, double lon_deg, double h, double& x, double& y, double& z)
 {
     const double a = 6378137.0, f = 1.0 / 298.257223563, e2 = f * (2.0 - f), d2r = 0.017453292519943295769;
-    const double sp = sin(lat_deg * d2r), cp = cos(lat_deg * d2r), sl = sin(lon_deg * d2r), cl = cos(lon_deg * d2r);
-    const double Nn = a / sqrt(1.0 - e2 * sp * sp);
+    double sp, cp, sl, cl;
+    gsf_sincos(lat_deg * d2r, sp, cp); gsf_sincos(lon_deg * d2r, sl, cl);
+    const double Nn = a * fast_rsqrt(1.0 - e2 * sp * sp);                 // prime-vertical radius; the argument is in [0.9933, 1]
     x = (Nn + h) * cp * cl; y = (Nn + h) * cp * sl; z = (Nn * (1.0 - e2) + h) * sp;
 }
 GSF_HD EnuFrame enu_frame(double lat0_deg, double lon0_deg, double h0)

@@ -31,7 +31,11 @@ ms = timed(lambda: B.utm_inverse_batch(e, nn, offs, zone, south))
 out["K1_utm_inverse_1e8pts"] = {"ms": ms, "Gpts_s": nb * n / ms / 1e6, "alg_GBps": nb * n * 32 / ms / 1e6}
 ms = timed(lambda: B.utm_forward_batch(lat, lon, offs))
 out["K1_zone_pick_plus_forward"] = {"ms": ms}
-del lat, lon, e, nn
+alt = 110.0 + torch.rand(nb * n, dtype=torch.float64, device=dev, generator=g)
+ref = torch.tensor([[49.03, 8.39, 110.0]], dtype=torch.float64, device=dev).repeat(nb, 1)
+ms = timed(lambda: B.geodetic_to_enu_batch(lat, lon, alt, offs, ref))
+out["K1b_geodetic_to_enu_1e8pts"] = {"ms": ms, "Gpts_s": nb * n / ms / 1e6, "alg_GBps": nb * n * 48 / ms / 1e6}
+del lat, lon, e, nn, alt
 # ---- K2: C4 = 1M windows x 50 pairs
 nw, W = 1_000_000, 50
 src = torch.cumsum(torch.randn(nw, W, 3, dtype=torch.float64, device=dev, generator=g) * torch.tensor([0.05, 0.03, 1.4], dtype=torch.float64, device=dev), dim=1)
