@@ -227,3 +227,15 @@ def geodetic_to_enu_batch(lat, lon, alt, offsets, ref_llh):
     e, n, u = torch.empty_like(lat), torch.empty_like(lat), torch.empty_like(lat)
     check(_lib.load().gsf_geodetic_to_enu_batch_dev(context().handle, _p(lat), _p(lon), _p(alt), _p(offsets), _p(ref_llh), B, _p(e), _p(n), _p(u)))
     return e, n, u
+
+
+def ransac_poly_batch(t, y, offsets, sample_idx, degree, residual_threshold, stop_probability=0.99):
+    """next-3 kernel over device tensors: P polynomial-RANSAC problems (rows offsets[p]..offsets[p+1] of t, y), sample sets
+    sample_idx (P, max_trials, min_samples) int32 drawn by the caller.  Returns inlier_mask (rows,) uint8, n_trials, n_inliers,
+    status (P,) int32 -- see gsf_ransac_poly_batch_dev."""
+    P, trials, ms = sample_idx.shape
+    mask = torch.empty((t.shape[0],), dtype=torch.uint8, device=t.device)
+    ntr, nin, st = (torch.empty((P,), dtype=torch.int32, device=t.device) for _ in range(3))
+    check(_lib.load().gsf_ransac_poly_batch_dev(context().handle, _p(t), _p(y), _p(offsets), P, _p(sample_idx), trials, ms, int(degree),
+                                                float(residual_threshold), float(stop_probability), _p(mask), _p(ntr), _p(nin), _p(st)))
+    return mask, ntr, nin, st

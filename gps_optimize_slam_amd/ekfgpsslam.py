@@ -112,34 +112,60 @@ class UtmProjector:
         return o2, o1        # gsf returns (lat, lon); pyproj returns (lon, lat)
 
 
+def _ransac_axes_mask(t, p, degree, min_samples, residual_threshold, max_trials):
+    """AND over the coordinate axes of one RANSACRegressor.fit each (ref :155-169), evaluated by gsf_ransac_poly_batch_dev.
+    The sample sets come from scikit-learn's own sampler on NumPy's global legacy RNG -- the call RANSACRegressor makes -- and
+    the stream is left exactly where the reference leaves it: the device returns n_trials_, the number of sets the reference's
+    loop would have drawn (its trial count is data dependent), and the draws are replayed from the saved state.
+    Raises ValueError when an axis finds no consensus set, like scikit-learn."""
+    import torch
+    from sklearn.utils.random import sample_without_replacement
+    from . import batch as B
+    rs = np.random.mtrand._rand                                          # check_random_state(None)
+    n = len(t)
+    dev = dict(device="cuda")
+    td = torch.as_tensor(np.ascontiguousarray(t, dtype=np.float64)).to(**dev)
+    offs = torch.tensor([0, n], dtype=torch.int64, **dev)
+    keep = np.ones(n, dtype=bool)
+    for ax in range(p.shape[1]):
+        state = rs.get_state()
+        idx = np.stack([sample_without_replacement(n, min_samples, random_state=rs) for _ in range(max_trials)]).astype(np.int32)
+        yd = torch.as_tensor(np.ascontiguousarray(p[:, ax], dtype=np.float64)).to(**dev)
+        mask, ntr, nin, st = B.ransac_poly_batch(td, yd, offs, torch.as_tensor(idx.reshape(1, max_trials, min_samples)).to(**dev),
+                                                 degree, residual_threshold)
+        ntr, st = int(ntr.item()), int(st.item())
+        rs.set_state(state)
+        for _ in range(ntr):
+            sample_without_replacement(n, min_samples, random_state=rs)
+        if st != 0:
+            raise ValueError("RANSAC could not find a valid consensus set.")
+        keep &= mask.cpu().numpy().astype(bool)
+    return keep
+
+
 def filter_gps_outliers_ransac(times, positions, config):
-    """Host-side restatement of the reference's optional GPS pre-filter (ref :136-247): per-axis degree-d polynomial
-    RANSAC (scikit-learn's RANSACRegressor, global legacy RNG), AND across axes; either one global fit or sliding
-    windows [t, t+W) advanced by W*step_factor with one extra tail window, OR across windows -- rows never inside a
-    fitted window are dropped.  SURVEY 8(f) next-3: not a kernel yet; needs scikit-learn exactly as the reference does."""
+    """The reference's optional GPS pre-filter (ref :136-247): per-axis degree-d polynomial RANSAC, AND
+    across axes; either one global fit or sliding windows [t, t+W) advanced by W*step_factor with one extra tail window, OR
+    across windows -- rows never inside a fitted window are dropped.  The RANSAC itself (the reference's scikit-learn
+    RANSACRegressor over PolynomialFeatures + LinearRegression) runs on the GPU (gsf_ransac_poly_batch_dev); only the sample sets
+    are drawn on the host, with scikit-learn's sampler on the global legacy RNG, so a seeded run keeps the same rows and leaves
+    the RNG in the same state as the reference."""
     if not config.get("enabled", False):
         return times, positions
     n_points, need = len(times), config["min_samples"]
     if n_points < need:
         return times, positions
-    from sklearn.linear_model import RANSACRegressor
-    from sklearn.pipeline import make_pipeline
-    from sklearn.preprocessing import PolynomialFeatures
+    degree, thr, trials = config["polynomial_degree"], config["residual_threshold_meters"], config["max_trials"]
 
     def axes_mask(t, p):
-        per_axis = []
-        for ax in range(positions.shape[1]):
-            model = make_pipeline(PolynomialFeatures(degree=config["polynomial_degree"]),
-                                  RANSACRegressor(min_samples=need, residual_threshold=config["residual_threshold_meters"],
-                                                  max_trials=config["max_trials"]))
-            model.fit(t.reshape(-1, 1), p[:, ax])
-            per_axis.append(model[-1].inlier_mask_)
-        return np.logical_and.reduce(per_axis)
+        return _ransac_axes_mask(np.asarray(t, dtype=np.float64), np.asarray(p, dtype=np.float64), degree, need, thr, trials)
 
     if not config.get("use_sliding_window", False):                      # ref :148-182
         try:
             keep = axes_mask(times, positions)
             return times[keep], positions[keep]
+        except GsfError:
+            raise
         except Exception:
             return times, positions
     width = config["window_duration_seconds"]                            # ref :183-247
@@ -153,6 +179,8 @@ def filter_gps_outliers_ransac(times, positions, config):
         if len(rows) >= need:
             try:
                 keep[rows[axes_mask(times[rows], positions[rows])]] = True
+            except GsfError:
+                raise
             except Exception:
                 pass                                                     # a failed window marks nothing (ref :228-229)
         if stride <= 1e-6:

@@ -121,6 +121,18 @@ GSF_API int gsf_utm_inverse(gsf_ctx *ctx, const double *easting, const double *n
 GSF_API int gsf_geodetic_to_enu_batch_dev(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const double *alt, const int64_t *offsets,
                                           const double *ref_llh, int64_t B, double *east, double *north, double *up);
 
+/* ---- next-3: GPS outlier pre-filter (filter_gps_outliers_ransac, EKFGPSSLAM.py:136-247) ------------------------------------
+   One problem = one RANSACRegressor.fit of the reference (one window x one coordinate axis): rows offsets[p]..offsets[p+1] of
+   (t, y).  sample_idx[P][max_trials][min_samples] are the sample sets of every trial, drawn by the host with scikit-learn's
+   sample_without_replacement on NumPy's legacy RNG (the call of sklearn/linear_model/_ransac.py), so a seeded run reproduces the
+   reference.  Per problem: inlier_mask over its rows (|y - poly(t)| <= residual_threshold for the accepted model), n_trials (the
+   number of sample sets scikit-learn's loop would have consumed: acceptance rule + dynamic trial count with stop_probability),
+   n_inliers, status (0 = ok, 1 = no consensus set: the reference's ValueError).  degree 1..3, min_samples <= 16, max_trials <= 128. */
+GSF_API int gsf_ransac_poly_batch_dev(gsf_ctx *ctx, const double *t, const double *y, const int64_t *offsets, int64_t P,
+                                      const int32_t *sample_idx, int32_t max_trials, int32_t min_samples, int32_t degree,
+                                      double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,
+                                      int32_t *n_inliers, int32_t *status);
+
 /* ---- K2: Sim3 / Umeyama (compute_sim3_transform, EKFGPSSLAM.py:428-459) ------------------- */
 /* B ragged point sets: src/dst are [total][3]; offsets int64[B+1].  Optional `mask` (uint8[total], may be NULL)
    selects the rows that take part (used for "valid GNSS only" fits).  Outputs R[B][9] (row-major), t[B][3],

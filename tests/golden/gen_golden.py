@@ -529,7 +529,63 @@ def gen_align_cases(slam):
     save("align_cases.npz", **out)
 
 
+# --------------------------------------------------------------------------
+def gen_filter_cases():
+    """filter_gps_outliers_ransac (ref :136-247, scikit-learn's RANSACRegressor on the global legacy RNG): inputs, config, seed ->
+    the kept rows and one np.random.random() drawn right after the call (pins how much of the RNG stream was consumed)."""
+    rng = np.random.default_rng(11)
+    out, names = {}, []
+    base = {"enabled": True, "use_sliding_window": True, "window_duration_seconds": 15.0, "window_step_factor": 0.5,
+            "polynomial_degree": 2, "min_samples": 6, "residual_threshold_meters": 10.0, "max_trials": 50}
+
+    def add(name, t, p, seed, **over):
+        cfg = dict(base); cfg.update(over)
+        np.random.seed(seed)
+        with quiet():
+            ft, fp = ref.filter_gps_outliers_ransac(t.copy(), p.copy(), cfg)
+        after = np.random.random()
+        out.update({f"{name}_t": t, f"{name}_p": p, f"{name}_seed": np.int64(seed), f"{name}_ft": np.array(ft), f"{name}_fp": np.array(fp),
+                    f"{name}_after": np.float64(after),
+                    f"{name}_cfg": np.array([cfg["use_sliding_window"], cfg["window_duration_seconds"], cfg["window_step_factor"], cfg["polynomial_degree"],
+                                             cfg["min_samples"], cfg["residual_threshold_meters"], cfg["max_trials"]], dtype=np.float64)})
+        names.append(name)
+
+    for tag, f in (("kitti04gps", f"{REF}/5.1Kitti04gps"), ("combined", f"{REF}/combined_output.txt")):
+        raw = np.loadtxt(f)
+        e, n = orc.utm_forward(raw[:, 1], raw[:, 2], 32, False)
+        add(f"bundled_{tag}", raw[:, 0], np.column_stack((e, n, raw[:, 3])), 0)
+
+    def track(n, n_out, spike=(30.0, 200.0), noise=0.5):
+        t = np.arange(n) * 0.1 + rng.uniform(-0.01, 0.01, n); t[0] = 0.0
+        p = np.c_[4.5e5 + 12.0 * t + 30 * np.sin(t / 7), 5.4e6 + 3.0 * t + 0.2 * t * t, 110 + np.cos(t / 5)] + rng.normal(0, noise, (n, 3))
+        bad = rng.choice(n, n_out, replace=False)
+        p[bad] += rng.choice([-1.0, 1.0], (n_out, 3)) * rng.uniform(spike[0], spike[1], (n_out, 3)) * (rng.random((n_out, 3)) < 0.6)
+        return t, p
+
+    t, p = track(300, 15)
+    add("spikes_s1", t, p, 1); add("spikes_s2", t, p, 2)
+    add("spikes_global", t, p, 3, use_sliding_window=False)
+    add("spikes_deg1", t, p, 4, polynomial_degree=1, residual_threshold_meters=25.0)
+    add("spikes_deg3", t, p, 5, polynomial_degree=3, min_samples=8)
+    add("tight_thr", t, p, 6, residual_threshold_meters=1.2, max_trials=100)
+    add("few_trials", t, p, 7, max_trials=5, min_samples=4)
+    t2, p2 = track(400, 160, spike=(15.0, 60.0))
+    add("heavy_outliers", t2, p2, 8)
+    add("heavy_outliers_global", t2, p2, 9, use_sliding_window=False, max_trials=100)
+    add("too_few_points", t[:5], p[:5], 10)
+    add("short_windows", t[::12], p[::12], 11, window_duration_seconds=4.0)          # windows with fewer than min_samples rows
+    add("zero_stride", t[:80], p[:80], 12, window_step_factor=0.0, window_duration_seconds=3.0)
+    perm = rng.permutation(300)
+    add("unsorted", t[perm], p[perm], 13)
+    add("disabled", t, p, 14, enabled=False)
+    out["names"] = np.array(names)
+    save("gpsfilter_cases.npz", **out)
+
+
 if __name__ == "__main__":
+    if "--only-filter" in sys.argv:                  # later additions regenerate alone: the other files stay byte-identical
+        gen_filter_cases()
+        sys.exit(0)
     slam = gen_kat_bundled()
     gen_c1(slam, f"{REF}/5.1Kitti04gps", "kitti04gps")
     gen_c1(slam, f"{REF}/combined_output.txt", "combined")
@@ -537,3 +593,4 @@ if __name__ == "__main__":
     gen_ekf_cases()
     gen_helper_cases()
     gen_align_cases(slam)
+    gen_filter_cases()

@@ -709,3 +709,45 @@ def test_random_outage_patterns_every_kernel_vs_oracle(B, orc, N):
                 ctx.set_option(key, 0)
         np.testing.assert_array_equal(st, sto, err_msg=f"{key} {val}")
         assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL, (key, val, np.abs(p - po).max())
+
+
+def test_gps_ransac_filter_vs_reference_goldens(E, golden):
+    """next-3: filter_gps_outliers_ransac with the RANSAC on the GPU against runs of the reference itself (scikit-learn's
+    RANSACRegressor, seeded global RNG): the same rows kept, bit for bit, and the RNG left in the same state (the draw that follows)."""
+    g = golden("gpsfilter_cases.npz")
+    for name in g["names"]:
+        sliding, width, stepf, deg, ms, thr, trials = g[f"{name}_cfg"]
+        cfg = {"enabled": name != "disabled", "use_sliding_window": bool(sliding), "window_duration_seconds": float(width),
+               "window_step_factor": float(stepf), "polynomial_degree": int(deg), "min_samples": int(ms),
+               "residual_threshold_meters": float(thr), "max_trials": int(trials)}
+        np.random.seed(int(g[f"{name}_seed"]))
+        ft, fp = E.filter_gps_outliers_ransac(g[f"{name}_t"].copy(), g[f"{name}_p"].copy(), cfg)
+        after = np.random.random()
+        np.testing.assert_array_equal(ft, g[f"{name}_ft"], err_msg=name)
+        np.testing.assert_array_equal(fp, g[f"{name}_fp"], err_msg=name)
+        assert after == float(g[f"{name}_after"]), (name, "RNG stream position differs from the reference's")
+
+
+def test_ransac_poly_batch_kernel(B):
+    """The batched entry: many problems in one launch agree with the same problems launched one by one; no-consensus status."""
+    import torch
+    rng = np.random.default_rng(3)
+    P, n, trials, ms = 300, 150, 50, 6
+    t = np.tile(np.arange(n) * 0.1, P) + rng.uniform(0, 0.01, P * n)
+    y = 5.4e6 + 3.0 * t + 0.2 * t * t + rng.normal(0, 0.5, P * n)
+    bad = rng.random(P * n) < 0.1
+    y[bad] += rng.choice([-1, 1], bad.sum()) * rng.uniform(30, 200, bad.sum())
+    offs = np.arange(0, (P + 1) * n, n, dtype=np.int64)
+    idx = np.stack([np.stack([rng.choice(n, ms, replace=False) for _ in range(trials)]) for _ in range(P)]).astype(np.int32)
+    d = lambda a: torch.as_tensor(a).cuda()
+    mask, ntr, nin, st = B.ransac_poly_batch(d(t), d(y), d(offs), d(idx), 2, 10.0)
+    mask, ntr, nin, st = mask.cpu().numpy(), ntr.cpu().numpy(), nin.cpu().numpy(), st.cpu().numpy()
+    assert (st == 0).all() and (ntr >= 1).all() and (ntr <= trials).all()
+    assert (mask.reshape(P, n).sum(axis=1) == nin).all()
+    assert (mask.astype(bool) & bad).sum() < 0.02 * bad.sum()          # the spikes are rejected
+    for p in (0, 17, 299):
+        m1, n1, i1, s1 = B.ransac_poly_batch(d(t[p * n:(p + 1) * n].copy()), d(y[p * n:(p + 1) * n].copy()), d(np.array([0, n], dtype=np.int64)), d(idx[p:p + 1].copy()), 2, 10.0)
+        np.testing.assert_array_equal(m1.cpu().numpy(), mask[p * n:(p + 1) * n]); assert int(n1.item()) == ntr[p]
+    # an impossible threshold: every trial has zero inliers -> status 1, empty mask, all trials consumed
+    m0, n0, i0, s0 = B.ransac_poly_batch(d(t[:n].copy()), d(y[:n].copy()), d(np.array([0, n], dtype=np.int64)), d(idx[:1].copy()), 2, -1.0)
+    assert int(s0.item()) == 1 and int(n0.item()) == trials and int(m0.sum().item()) == 0

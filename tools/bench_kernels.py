@@ -69,4 +69,15 @@ p = lambda x: C.c_void_p(x.data_ptr())
 L, h = _lib.load(), B.context().handle
 ms = timed(lambda: _lib.check(L.gsf_time_align_batch_dev(h, p(st), p(so), p(gt), p(gp), p(go), nt, 512, 5.0, p(al), p(va), None)))
 out["align_1000traj_271x279"] = {"ms": ms, "Mposes_s": nt * npts / ms / 1e3}
+# ---- next-3: polynomial RANSAC of the GPS pre-filter: 30 000 problems (10 000 windows x 3 axes) of 150 rows, 50 fed trials of 6 samples
+P, n, trials, ms = 30_000, 150, 50, 6
+t = (torch.arange(n, dtype=torch.float64, device=dev) * 0.1).repeat(P) + 0.01 * torch.rand(P * n, dtype=torch.float64, device=dev, generator=g)
+y = 5.4e6 + 3.0 * t + 0.2 * t * t + 0.5 * torch.randn(P * n, dtype=torch.float64, device=dev, generator=g)
+spike = torch.rand(P * n, dtype=torch.float64, device=dev, generator=g) < 0.1
+y = y + spike * 100.0
+offs = torch.arange(0, (P + 1) * n, n, dtype=torch.int64, device=dev)
+idx = torch.argsort(torch.rand(P, trials, n, device=dev, generator=g), dim=2)[:, :, :ms].to(torch.int32).contiguous()
+ms_t = timed(lambda: B.ransac_poly_batch(t, y, offs, idx, 2, 10.0))
+out["next3_ransac_poly_30k_problems_150rows_50trials"] = {"ms": ms_t, "problems_per_s": P / ms_t * 1e3, "residual_evals_per_s": P * trials * n * 2 / ms_t * 1e3}
+del t, y, offs, idx, spike
 print(json.dumps(out, indent=1))
