@@ -751,3 +751,38 @@ def test_ransac_poly_batch_kernel(B):
     # an impossible threshold: every trial has zero inliers -> status 1, empty mask, all trials consumed
     m0, n0, i0, s0 = B.ransac_poly_batch(d(t[:n].copy()), d(y[:n].copy()), d(np.array([0, n], dtype=np.int64)), d(idx[:1].copy()), 2, -1.0)
     assert int(s0.item()) == 1 and int(n0.item()) == trials and int(m0.sum().item()) == 0
+
+
+def test_gps_ransac_problems_vs_live_sklearn(E):
+    """Randomised next-3 problems against scikit-learn itself (the reference's dependency), run live with the same seed: inlier
+    mask, and the RNG position afterwards, for degrees 1-3, 4-10 samples, thresholds from tight to loose, 0-45 % outliers.
+    Stamps are track-relative (0..130 s, as in the reference's data): with epoch-sized stamps the monomial features t^2, t^3 are
+    collinear to ~1e-12 and LAPACK's truncated-SVD solve is not reproducible by any other solver."""
+    from sklearn.linear_model import RANSACRegressor
+    from sklearn.pipeline import make_pipeline
+    from sklearn.preprocessing import PolynomialFeatures
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        n = int(rng.integers(12, 260)); deg = int(rng.integers(1, 4)); ms = int(rng.integers(max(deg + 1, 4), 11))
+        thr = float(rng.choice([0.8, 2.0, 10.0, 50.0])); trials = int(rng.choice([5, 50, 100]))
+        t = np.sort(rng.uniform(0, 30, n)) + (0.0 if case % 3 else 100.0)
+        y = 5.4e6 + 3.0 * (t - t[0]) + 0.2 * (t - t[0]) ** 2 + rng.normal(0, 0.4, n)
+        bad = rng.random(n) < rng.uniform(0, 0.45)
+        y[bad] += rng.choice([-1, 1], bad.sum()) * rng.uniform(5, 300, bad.sum())
+        np.random.seed(case)
+        model = make_pipeline(PolynomialFeatures(degree=deg), RANSACRegressor(min_samples=ms, residual_threshold=thr, max_trials=trials))
+        try:
+            model.fit(t.reshape(-1, 1), y); ref_mask = model[-1].inlier_mask_
+        except ValueError:
+            ref_mask = None
+        ref_after = np.random.random()
+        np.random.seed(case)
+        try:
+            mask = E._ransac_axes_mask(t, y.reshape(-1, 1), deg, ms, thr, trials)
+        except ValueError:
+            mask = None
+        after = np.random.random()
+        assert (mask is None) == (ref_mask is None), case
+        if mask is not None:
+            np.testing.assert_array_equal(mask, ref_mask, err_msg=f"case {case}: n={n} deg={deg} ms={ms} thr={thr}")
+        assert after == ref_after, case
