@@ -81,7 +81,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     if (device_id < 0 || device_id >= n) { set_error("gsf_create: device %d out of range [0,%d)", device_id, n); return GSF_ERR_INVALID_ARG; }
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
-    c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->ekf_variant = 0; c->wave_ppl = 0; c->seg_kernel = 0;
+    c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->ekf_variant = 0; c->wave_ppl = 0; c->seg_kernel = 0; c->duo_kernel = -1;
     if (owns) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail_hip(e, "hipStreamCreateWithFlags"); }
@@ -119,6 +119,10 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
 {
     GSF_REQUIRE(ctx && key, "NULL argument");
     if (strcmp(key, "ekf_variant") == 0) { ctx->ekf_variant = (int)value; return GSF_OK; }
+    if (strcmp(key, "duo_kernel") == 0) {
+        if (value < -1 || value > 1) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 or 1"); return GSF_ERR_INVALID_ARG; }
+        ctx->duo_kernel = (int)value; return GSF_OK;
+    }
     if (strcmp(key, "seg_kernel") == 0) {
         if (value < 0 || value > 1) { set_error("gsf_set_option: seg_kernel must be 0 or 1"); return GSF_ERR_INVALID_ARG; }
         ctx->seg_kernel = (int)value; return GSF_OK;

@@ -29,6 +29,25 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 }
 
 
+// Two waves per trajectory for SMALL batches of the fused pipeline (one wave per SIMD, every wave in the same phase at the same
+// time): while wave 0 is busy with the fit -- a memory burst followed by a latency-bound 3x3 Jacobi chain that leave the SIMD
+// mostly idle -- wave 1 computes the variances of EVERY chunk (they depend on stamps and availability only, not on the fit) into
+// LDS; after one block barrier wave 0 runs the chunk loop without its two Moebius scans (-28 % instructions per chunk).
+// Same functions, same operands, same order as the one-wave kernel: bit-identical results.
+template <bool PIPELINE>
+__global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig cfg, int pv_stride)
+{
+    extern __shared__ double gsf_pv[];
+    const int lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x >= 64) {
+        wave_variance_helper(a, cfg, b, lane, gsf_pv, pv_stride);
+        __syncthreads();
+        return;
+    }
+    wave_serial_body<PIPELINE, true>(a, cfg, b, lane, gsf_pv, pv_stride);
+}
+
 // Several poses per lane: an iteration takes 64 * P consecutive poses, P = min(PPLMAX, ceil(remaining / 64)), lane l owning the P
 // consecutive poses l*P .. l*P+P-1 (process_chunk<P>: in-lane composition, ONE set of DPP scans per iteration, in-lane
 // application).  A track of up to 64 * PPLMAX poses is a single iteration with no chunk-to-chunk carry at all.  The wave executes
@@ -110,6 +129,17 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
         return launch_ekf_seg(ctx, pipeline, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status);
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
+    // small batches of the fused pipeline: two waves per trajectory (see ekf_wave_duo_kernel).  Bit-identical to the one-wave
+    // kernel, so choosing by batch size does not break shard invariance.  gsf_set_option "duo_kernel": -1 automatic, 0 never, 1 always.
+    // Measured (pipeline, N = 271): 17.9 vs 20.5 us at 250 tracks, 20.7 vs 21.9 us at 500, no gain at 1 000 (every SIMD then holds
+    // two waves and the total instruction count decides), slower beyond -- automatic = up to 512 tracks.
+    if (pipeline && !offsets && ctx->wave_ppl == 0 && ctx->ekf_variant == 0 && ctx->duo_kernel != 0 && N > 64 && N <= 640 &&
+        (ctx->duo_kernel == 1 || B <= 512)) {
+        const int stride = (int)((N + 1) & ~(int64_t)1);
+        hipLaunchKernelGGL(ekf_wave_duo_kernel<true>, dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
+        GSF_HIP(hipGetLastError());
+        return GSF_OK;
+    }
     // Poses per lane (gsf_set_option "wave_ppl": 0 = automatic, 1..5 forced).  Automatic is ONE pose per lane with a register
     // prefetch at every batch size.  The multi-pose builds (process_chunk<P>) pass the same parity tests but measured slower on
     // MI355X everywhere: C2 K4 18.1 / 21.1 / 21.6 / 25.1 / 30.0 us for P = 1..5, and worse at large batches (2 waves or fewer per

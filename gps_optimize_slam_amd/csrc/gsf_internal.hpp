@@ -17,6 +17,7 @@ struct gsf_ctx {
     size_t scratch_bytes;
     int ekf_variant;       // tuning knob (gsf_set_option "ekf_variant")
     int wave_ppl;          // poses per lane of the wave-per-trajectory kernels (gsf_set_option "wave_ppl"; 0 = automatic)
+    int duo_kernel;        // two-wave pipeline kernel for small batches (gsf_set_option "duo_kernel"): -1 automatic, 0 never, 1 always
     int seg_kernel;        // single-shot kernel for short tracks (gsf_set_option "seg_kernel"): 1 = whenever N fits, otherwise never (opt-in)
 };
 

@@ -332,9 +332,89 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
     return true;
 }
 
+// Variances of one 64-pose chunk (ref :712-713, :723-731): prefix composition of the Moebius maps P -> (A P + Bm)/(Cm P + Dm) per
+// axis, carry-in cP.  Axes with identical (P0, Q, R) have identical recursions and reuse the scan (default CONFIG: x == y).
+// One function for the chunked body AND the helper wave of the two-wave kernel, so that both produce the same bits.
+struct AxisVar { double Pf, Pm, kg; };
+__device__ __forceinline__ AxisVar variance_axis(const double q, const double rr, const double dt, const bool stepping, const bool avail, const double cPc)
+{
+    const double b0 = q * dt;
+    double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
+    if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
+    // mine (later) o other (earlier); lanes without a source see the identity map (1,0;0,1)
+#define GSF_MSTAGE(CTRL, RM) {                                                                                              \
+        const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp0<CTRL, RM>(Bm), oC = dpp0<CTRL, RM>(Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
+        const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
+        A = nA; Bm = nB; Cm = nC; Dm = nD; }
+    GSF_SCAN_STAGES(GSF_MSTAGE)
+#undef GSF_MSTAGE
+    AxisVar v;
+    v.Pf = (A * cPc + Bm) * fast_rcp(Cm * cPc + Dm);                     // P_f[i]
+    v.Pm = prev_lane(cPc, v.Pf) + b0;                                    // P_p[i]
+    v.kg = v.Pm * fast_rcp(v.Pm + rr);                                   // Kalman gain if the fix is used
+    return v;
+}
+// (scalar arguments and constant indices only: a helper that indexes its caller's arrays dynamically puts them into scratch)
+__device__ __forceinline__ void variance_chunk(const EkfConfig& cfg, const int same1, const int same2, const double dt, const bool stepping,
+                                               const bool avail, const double cP0, const double cP1, const double cP2,
+                                               AxisVar& v0, AxisVar& v1, AxisVar& v2)
+{
+    v0 = variance_axis(cfg.Qps[0], cfg.Rm[0], dt, stepping, avail, cP0);
+    if (same1 == 0) v1 = v0; else v1 = variance_axis(cfg.Qps[1], cfg.Rm[1], dt, stepping, avail, cP1);
+    if (same2 == 0) v2 = v0; else if (same2 == 1) v2 = v1; else v2 = variance_axis(cfg.Qps[2], cfg.Rm[2], dt, stepping, avail, cP2);
+}
+
+// The helper wave of the two-wave kernel: variances of EVERY chunk of the track, written to LDS (pv[(axis*3 + {Pf,Pm,kg}) * stride
+// + pose]) while the main wave is busy with the fit.  It reads only what the variance recursion depends on: stamps, mask, NaN-ness
+// of the fixes.  Same flags, same dt, same variance_chunk() as the chunked body.
+__device__ __forceinline__ void wave_variance_helper(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane, double* pv, const int pv_stride)
+{
+    int64_t base, N; traj_span(a, b, base, N);
+    if (N <= 0) return;
+    const double* __restrict__ tsb = a.ts + base;
+    const double* __restrict__ gpsb = a.gps + base * 3;
+    const uint8_t* __restrict__ valb = a.valid + base;
+    int same_axis[3] = { -1, -1, -1 };
+    if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
+    if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
+    else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
+    double cP[3] = { cfg.P0[0], cfg.P0[1], cfg.P0[2] };
+    double c_t = tsb[0];
+    // the next chunk's rows are requested before the current chunk's scans (this wave must finish inside the main wave's fit)
+    struct HIn { double t, z0, z1, z2; uint32_t v; };
+    auto hload = [&](const int64_t i) __attribute__((always_inline)) {
+        const int64_t il = i < N ? i : N - 1;
+        return HIn{ tsb[il], gpsb[il * 3], gpsb[il * 3 + 1], gpsb[il * 3 + 2], valb[il] };
+    };
+    HIn nx = hload(lane);
+    for (int64_t c0 = 0; c0 < N; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool active = i < N, stepping = active && i != 0;
+        const int L = (int)((N - c0 < 64) ? (N - c0 - 1) : 63);
+        const HIn in = nx;
+        if (c0 + 64 < N) nx = hload(c0 + 64 + lane);
+        const double t = in.t, z0 = in.z0, z1 = in.z1, z2 = in.z2;
+        const bool vraw = in.v != 0;
+        const double dt = fmax(1e-6, t - prev_lane(c_t, t));             // ref :865
+        const bool avail = stepping && vraw && !(isnan(z0) || isnan(z1) || isnan(z2));   // ref :867-869
+        AxisVar v0, v1, v2;
+        variance_chunk(cfg, same_axis[1], same_axis[2], dt, stepping, avail, cP[0], cP[1], cP[2], v0, v1, v2);
+        const double Pf[3] = { v0.Pf, v1.Pf, v2.Pf }, Pm[3] = { v0.Pm, v1.Pm, v2.Pm }, kg[3] = { v0.kg, v1.kg, v2.kg };
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pv[(c * 3 + 0) * pv_stride + i] = Pf[c]; pv[(c * 3 + 1) * pv_stride + i] = Pm[c]; pv[(c * 3 + 2) * pv_stride + i] = kg[c]; }
+        }
+        cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
+        c_t = lane_bcast(t, L);
+    }
+}
+
 // One wave walks trajectory `b` 64 poses at a time (serial over chunks, scans inside a chunk).
-template <bool PIPELINE>
-__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane)
+// PREVAR (two-wave kernel): the variances come from LDS (pv, written by wave_variance_helper) once the block barrier after the
+// fit has been passed; everything else is identical, so the two kernels produce the same bits.
+template <bool PIPELINE, bool PREVAR = false>
+__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
+                                                 const double* pv = nullptr, const int pv_stride = 0)
 {
     GSF_STAMP(0);
     int64_t base, N; traj_span(a, b, base, N);
@@ -350,8 +430,9 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
     ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) return;
+    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) return;   // (a returning wave no longer counts at the barrier)
     GSF_STAMP(6);
+    if (PREVAR) __syncthreads();                                         // the helper wave has written every chunk's variances
 
     // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
     Quat cq = ekf_normalize(q0);                                         // ref :842, :683
@@ -470,25 +551,16 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
             u = quat_rotate(q_prev, dpl);
         }
 
-        // ---- variances: prefix composition of Moebius maps P -> (A P + Bm)/(Cm P + Dm) per axis (ref :712-713, :723-731)
+        // ---- variances (ref :712-713, :723-731): scanned here, or -- PREVAR -- already computed by the helper wave (LDS)
         double Pf[3], Pm[3], kg[3];
+        if (PREVAR) {
+            const int64_t il = active ? i : N - 1;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            // axes with identical (P0, Q, R) have identical variance recursions: reuse the scan (default CONFIG: x == y)
-            if (c > 0 && same_axis[c] >= 0) { const int o = same_axis[c]; Pf[c] = Pf[o]; Pm[c] = Pm[o]; kg[c] = kg[o]; continue; }
-            const double b0 = cfg.Qps[c] * dt, rr = cfg.Rm[c];
-            double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
-            if (avail) { A = rr; Bm = rr * b0; Cm = 1.0; Dm = b0 + rr; }
-            // mine (later) o other (earlier); lanes without a source see the identity map (1,0;0,1)
-#define GSF_MSTAGE(CTRL, RM) {                                                                                              \
-                const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp0<CTRL, RM>(Bm), oC = dpp0<CTRL, RM>(Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
-                const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
-                A = nA; Bm = nB; Cm = nC; Dm = nD; }
-            GSF_SCAN_STAGES(GSF_MSTAGE)
-#undef GSF_MSTAGE
-            Pf[c] = (A * cP[c] + Bm) * fast_rcp(Cm * cP[c] + Dm);        // P_f[i]
-            Pm[c] = prev_lane(cP[c], Pf[c]) + b0;                        // P_p[i]
-            kg[c] = Pm[c] * fast_rcp(Pm[c] + rr);                        // Kalman gain if the fix is used
+            for (int c = 0; c < 3; ++c) { Pf[c] = pv[(c * 3 + 0) * pv_stride + il]; Pm[c] = pv[(c * 3 + 1) * pv_stride + il]; kg[c] = pv[(c * 3 + 2) * pv_stride + il]; }
+        } else {
+            AxisVar v0, v1, v2;
+            variance_chunk(cfg, same_axis[1], same_axis[2], dt, stepping, avail, cP[0], cP[1], cP[2], v0, v1, v2);
+            Pf[0] = v0.Pf; Pf[1] = v1.Pf; Pf[2] = v2.Pf; Pm[0] = v0.Pm; Pm[1] = v1.Pm; Pm[2] = v2.Pm; kg[0] = v0.kg; kg[1] = v1.kg; kg[2] = v2.kg;
         }
 
         // ---- positions: prefix composition of affine maps x -> al x + be in chunk-local coordinates (x = p - p_carry)

@@ -786,3 +786,21 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         if mask is not None:
             np.testing.assert_array_equal(mask, ref_mask, err_msg=f"case {case}: n={n} deg={deg} ms={ms} thr={thr}")
         assert after == ref_after, case
+
+
+def test_two_wave_pipeline_kernel_is_bit_identical(B):
+    """The two-wave pipeline kernel (helper wave computes every chunk's variances during the fit) runs the same functions on the
+    same operands as the one-wave kernel: identical bits, so the automatic choice by batch size cannot change results."""
+    for N in (65, 271, 640):
+        batch = B.TrajectoryBatch.synthetic(500, N, layout=0, seed=31)
+        batch.quat[7, N // 3] = 0.0                                     # one track on the generic (bad quaternion) path
+        res = {}
+        for duo in (0, 1):
+            B.context().set_option("duo_kernel", duo)
+            try:
+                out, R, t, s = B.fuse_pipeline_batch(batch)
+                res[duo] = out.host_traj_major() + (R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy())
+            finally:
+                B.context().set_option("duo_kernel", -1)
+        for x0, x1 in zip(res[0], res[1]):
+            np.testing.assert_array_equal(x0, x1)
