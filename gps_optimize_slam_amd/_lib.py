@@ -7,7 +7,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgsf.so")
+_SO = os.environ.get("GSF_LIBRARY") or os.path.join(_HERE, "libgsf.so")      # GSF_LIBRARY: A/B a differently built libgsf.so
 
 LAYOUT_TRAJ_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1

@@ -32,11 +32,18 @@ for (nb, n) in shapes:
         # 0 = default (automatic); 1..5 = forced poses per lane; 8 = chunk-parallel block kernel
         ctx.set_option("ekf_variant", 8 if v == 8 else 0)
         ctx.set_option("wave_ppl", v if 1 <= v <= 5 else 0)
-        ctx.set_option("duo_kernel", {6: 0, 7: 1}.get(v, -1))          # 6 = two-wave pipeline kernel off, 7 = forced on
+        try:
+            ctx.set_option("duo_kernel", {6: 0, 7: 1}.get(v, -1))      # 6 = two-wave pipeline kernel off, 7 = forced on
+        except Exception:
+            pass                                                        # an older library under GSF_LIBRARY (A/B runs)
         ms_e = timed(lambda: B.ekf_fuse_batch(bj, out=oj), reps)
         ms_p = timed(lambda: B.fuse_pipeline_batch(bj, out=oj), reps)
         print(json.dumps({"B": nb, "N": n, "variant": v, "ekf_us": round(ms_e * 1e3, 2), "pipeline_us": round(ms_p * 1e3, 2),
                           "ekf_frac": round(nb * n * 145 / (ms_e * 1e-3) / 8e12, 4), "pipeline_frac": round(nb * n * 145 / (ms_p * 1e-3) / 8e12, 4)}), flush=True)
-    ctx.set_option("ekf_variant", 0); ctx.set_option("wave_ppl", 0); ctx.set_option("duo_kernel", -1)
+    ctx.set_option("ekf_variant", 0); ctx.set_option("wave_ppl", 0)
+    try:
+        ctx.set_option("duo_kernel", -1)
+    except Exception:
+        pass
     del bj, oj
     torch.cuda.empty_cache()
