@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--layout", choices=["traj", "time"], default=None, help="traj = trajectory-major (wave-per-trajectory kernel), time = time-major (lane-per-trajectory kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra C3 / per-kernel measurements")
+    ap.add_argument("--set-option", action="append", default=[], metavar="KEY=VALUE", help="gsf_set_option tuning knob (e.g. duo_kernel=0)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,9 @@ def main():
     ctx = B.context()
     if args.ekf_variant is not None:
         ctx.set_option("ekf_variant", args.ekf_variant)
+    for kv in args.set_option:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
 
     def make_step(batch):
         out = B.FusedPoses(batch.layout, batch.B, batch.N, dev)

@@ -34,13 +34,19 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 // mostly idle -- wave 1 computes the variances of EVERY chunk (they depend on stamps and availability only, not on the fit) into
 // LDS; after one block barrier wave 0 runs the chunk loop without its two Moebius scans (-28 % instructions per chunk).
 // Same functions, same operands, same order as the one-wave kernel: bit-identical results.
+#ifndef GSF_DUO_ROLE_SHIFT
+#define GSF_DUO_ROLE_SHIFT 2        // measured best of 0..3 at 1 000 tracks (22.6 vs 23.1-23.2 us; 23.6 us without the helper)
+#endif
 template <bool PIPELINE>
 __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig cfg, int pv_stride)
 {
     extern __shared__ double gsf_pv[];
     const int lane = threadIdx.x & 63;
     const int64_t b = blockIdx.x;
-    if (threadIdx.x >= 64) {
+    // which wave of the block helps alternates with the block index: when two blocks share a pair of SIMDs, each SIMD then holds
+    // one main and one helper wave (complementary phases) instead of two of a kind
+    const bool helper = ((threadIdx.x >> 6) ^ ((blockIdx.x >> GSF_DUO_ROLE_SHIFT) & 1u)) != 0u;
+    if (helper) {
         wave_variance_helper(a, cfg, b, lane, gsf_pv, pv_stride);
         __syncthreads();
         return;
@@ -131,10 +137,11 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     const EkfConfig k = to_core(cfg);
     // small batches of the fused pipeline: two waves per trajectory (see ekf_wave_duo_kernel).  Bit-identical to the one-wave
     // kernel, so choosing by batch size does not break shard invariance.  gsf_set_option "duo_kernel": -1 automatic, 0 never, 1 always.
-    // Measured (pipeline, N = 271): 17.9 vs 20.5 us at 250 tracks, 20.7 vs 21.9 us at 500, no gain at 1 000 (every SIMD then holds
-    // two waves and the total instruction count decides), slower beyond -- automatic = up to 512 tracks.
+    // Measured (pipeline, N = 271): 17.5 vs 20.8 us at 250 tracks, 20.8 vs 21.9 us at 500; at 1 000 tracks within +-3 % of the one-wave
+    // kernel depending on the batch (22.4 vs 23.3 us on one, 24.6 vs 24.0 us on the bench's), slower from 2 000 on (every SIMD
+    // then holds several waves anyway) -- automatic = up to 768 tracks.
     if (pipeline && !offsets && ctx->wave_ppl == 0 && ctx->ekf_variant == 0 && ctx->duo_kernel != 0 && N > 64 && N <= 640 &&
-        (ctx->duo_kernel == 1 || B <= 512)) {
+        (ctx->duo_kernel == 1 || B <= 768)) {
         const int stride = (int)((N + 1) & ~(int64_t)1);
         hipLaunchKernelGGL(ekf_wave_duo_kernel<true>, dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
         GSF_HIP(hipGetLastError());
