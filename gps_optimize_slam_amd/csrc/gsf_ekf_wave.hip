@@ -46,6 +46,7 @@ __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig
     // which wave of the block helps alternates with the block index: when two blocks share a pair of SIMDs, each SIMD then holds
     // one main and one helper wave (complementary phases) instead of two of a kind
     const bool helper = ((threadIdx.x >> 6) ^ ((blockIdx.x >> GSF_DUO_ROLE_SHIFT) & 1u)) != 0u;
+    if (a.N <= 0) { if (!helper && lane == 0 && a.status) a.status[b] = 0; return; }   // empty tracks: both waves leave before any barrier
     if (helper) {
         wave_variance_helper(a, cfg, b, lane, gsf_pv, pv_stride);
         __syncthreads();

@@ -430,7 +430,10 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
     ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) return;   // (a returning wave no longer counts at the barrier)
+    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) {
+        if (PREVAR) __syncthreads();                                     // meet the helper wave at its barrier before leaving
+        return;
+    }
     GSF_STAMP(6);
     if (PREVAR) __syncthreads();                                         // the helper wave has written every chunk's variances
 

@@ -794,6 +794,8 @@ def test_two_wave_pipeline_kernel_is_bit_identical(B):
     for N in (65, 271, 640):
         batch = B.TrajectoryBatch.synthetic(500, N, layout=0, seed=31)
         batch.quat[7, N // 3] = 0.0                                     # one track on the generic (bad quaternion) path
+        batch.quat[9, 0] = 0.0                                          # pose-0 quaternion invalid: the main wave leaves right after the fit
+        batch.valid[11, :] = 0                                          # no usable fix at all: fit is None, same early exit
         res = {}
         for duo in (0, 1):
             B.context().set_option("duo_kernel", duo)
