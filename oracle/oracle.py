@@ -297,3 +297,87 @@ def dynamic_time_alignment(slam_t, gps_t, gps_p, max_samples=500, max_gap=5.0):
     va = np.zeros(max(st.size, 1), dtype=np.uint8)
     lib().orc_dynamic_time_alignment(st, st.size, gt, gp, gt.size, int(max_samples), float(max_gap), al, va)
     return al, va[:st.size].astype(bool)
+
+
+# ---- EKFGPSSLAM.py:136-247 (next-3) ------------------------------------------------------------------------------------------
+# The reference delegates to scikit-learn (pinned 1.7.2): make_pipeline(PolynomialFeatures(d), RANSACRegressor(min_samples,
+# residual_threshold, max_trials)) per window and per axis on NumPy's global legacy RNG.  Restated here in NumPy: the loop of
+# sklearn/linear_model/_ransac.py (RANSACRegressor.fit), LinearRegression as a centred least squares, r2_score, and
+# _dynamic_max_trials.  The ONE scikit-learn call kept is the sampler (sklearn.utils.random.sample_without_replacement on the global
+# RandomState): that is the reference's RNG consumption, not part of the algorithm.
+def _ransac_poly_fit(t, y, degree, min_samples, thr, max_trials, stop_probability=0.99):
+    from sklearn.utils.random import sample_without_replacement
+    rs = np.random.mtrand._rand
+    n = len(t)
+    X = np.vander(t, degree + 1, increasing=True)                       # [1, t, .., t^d]
+    eps = np.spacing(1)
+    best_mask, best_n, best_score, trials, max_tr = None, 1, -np.inf, 0, max_trials
+    while trials < max_tr:
+        trials += 1
+        idx = sample_without_replacement(n, min_samples, random_state=rs)
+        Xs, ys = X[idx], y[idx]
+        xo, yo = Xs.mean(axis=0), ys.mean()
+        coef = np.linalg.lstsq(Xs - xo, ys - yo, rcond=max(Xs.shape) * np.finfo(float).eps)[0]
+        pred = X @ coef + (yo - xo @ coef)
+        mask = np.abs(y - pred) <= thr
+        cnt = int(mask.sum())
+        if cnt < best_n:
+            continue
+        if cnt < 2:
+            score = np.nan                                               # r2_score of fewer than two samples
+        else:
+            yi, pi = y[mask], pred[mask]
+            num, den = ((yi - pi) ** 2).sum(), ((yi - yi.mean()) ** 2).sum()
+            score = 1.0 - num / den if den != 0.0 else (1.0 if num == 0.0 else 0.0)
+        if cnt == best_n and score < best_score:
+            continue
+        best_mask, best_n, best_score = mask, cnt, score
+        ratio = best_n / float(n)
+        nom, denom = max(eps, 1 - stop_probability), max(eps, 1 - ratio ** min_samples)
+        dyn = 0 if nom == 1 else (np.inf if denom == 1 else abs(float(np.ceil(np.log(nom) / np.log(denom)))))
+        max_tr = min(max_tr, dyn)
+    if best_mask is None:
+        raise ValueError("RANSAC could not find a valid consensus set")
+    return best_mask
+
+
+def filter_gps_outliers_ransac(times, positions, config):
+    """ref :136-247: per-axis polynomial RANSAC, AND across axes; global, or sliding windows OR-ed together."""
+    if not config.get("enabled", False):
+        return times, positions
+    n_points, need = len(times), config["min_samples"]
+    if n_points < need:
+        return times, positions
+    deg, thr, trials = config["polynomial_degree"], config["residual_threshold_meters"], config["max_trials"]
+
+    def axes_mask(t, p):
+        return np.logical_and.reduce([_ransac_poly_fit(t, p[:, ax], deg, need, thr, trials) for ax in range(p.shape[1])])
+
+    if not config.get("use_sliding_window", False):
+        try:
+            keep = axes_mask(times, positions)
+            return times[keep], positions[keep]
+        except Exception:
+            return times, positions
+    width = config["window_duration_seconds"]; stride = width * config["window_step_factor"]
+    keep = np.zeros(n_points, dtype=bool)
+    t_first, t_last = times[0], times[-1]
+    w0 = t_first
+    while w0 < t_last:
+        w1 = w0 + width
+        rows = np.where((times >= w0) & (times < w1))[0]
+        if len(rows) >= need:
+            try:
+                keep[rows[axes_mask(times[rows], positions[rows])]] = True
+            except Exception:
+                pass
+        if stride <= 1e-6:
+            later = np.where(times > w0)[0]
+            if len(later) == 0:
+                break
+            w0 = times[later[0]]
+        else:
+            w0 += stride
+        if w0 >= t_last and times[-1] >= w1:
+            w0 = max(t_first, times[-1] - width + 1e-6)
+    return times[keep], positions[keep]

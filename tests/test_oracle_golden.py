@@ -330,3 +330,20 @@ def test_enu_checker_vs_independent_form():
     # closed forms: a pure height change moves along Up only; the origin maps to 0
     e1, n1, u1 = orc.geodetic_to_enu([lat0, lat0], [lon0, lon0], [h0, h0 + 10.0], lat0, lon0, h0)
     np.testing.assert_allclose([e1[0], n1[0], u1[0], e1[1], n1[1], u1[1]], [0, 0, 0, 0, 0, 10.0], atol=1e-9)
+
+
+def test_gps_ransac_filter_goldens(golden):
+    """next-3: the oracle's NumPy restatement of scikit-learn's RANSACRegressor loop against runs of the reference itself: same rows
+    kept and the same RNG position afterwards, all 16 cases."""
+    g = golden("gpsfilter_cases.npz")
+    for name in g["names"]:
+        sliding, width, stepf, deg, ms, thr, trials = g[f"{name}_cfg"]
+        cfg = {"enabled": name != "disabled", "use_sliding_window": bool(sliding), "window_duration_seconds": float(width),
+               "window_step_factor": float(stepf), "polynomial_degree": int(deg), "min_samples": int(ms),
+               "residual_threshold_meters": float(thr), "max_trials": int(trials)}
+        np.random.seed(int(g[f"{name}_seed"]))
+        ft, fp = orc.filter_gps_outliers_ransac(g[f"{name}_t"].copy(), g[f"{name}_p"].copy(), cfg)
+        after = np.random.random()
+        np.testing.assert_array_equal(ft, g[f"{name}_ft"], err_msg=name)
+        np.testing.assert_array_equal(fp, g[f"{name}_fp"], err_msg=name)
+        assert after == float(g[f"{name}_after"]), name
