@@ -338,16 +338,19 @@ GSF_HD void utm_forward_point(const TmConsts& c, double lat_deg, double lon_deg,
     const double d2r = 0.017453292519943295769;
     const double phi = lat_deg * d2r, lam = lon_deg * d2r - lon0_deg * d2r;
     double sp, cp; gsf_sincos(phi, sp, cp);
-    const double t1 = 1.0 / cp, tau = sp * t1;                // tan(phi), sqrt(1 + tan^2)   (|phi| <= pi/2: cp >= 0)
+    // (1/x and 1/sqrt(x) by hardware seed + Newton: every operand here is a normal number of moderate size)
+    const double t1 = fast_rcp(cp), tau = sp * t1;            // sqrt(1 + tan^2), tan(phi)   (|phi| <= pi/2: cp > 0)
     const double sig = tm_sigma(c.e, sp);
-    const double taup = tau * sqrt(1.0 + sig * sig) - sig * t1;
+    const double os2 = 1.0 + sig * sig;
+    const double taup = tau * (os2 * fast_rsqrt(os2)) - sig * t1;
     double sl, cl; gsf_sincos(lam, sl, cl);
-    const double ih = 1.0 / sqrt(taup * taup + cl * cl);
+    const double ih = fast_rsqrt(taup * taup + cl * cl);
     const double xip = atan2(taup, cl);
     const double w = sl * ih;                                  // sinh(eta')
     const double etap = asinh_small(w);
     const double s1 = taup * ih, c1 = cl * ih;                 // sin(xi'), cos(xi')
-    const double ch1 = sqrt(1.0 + w * w);
+    const double ow2 = 1.0 + w * w;
+    const double ch1 = ow2 * fast_rsqrt(ow2);
     double a, b;
     tm_series(c.alpha, 2.0 * s1 * c1, (c1 - s1) * (c1 + s1), 2.0 * w * ch1, 1.0 + 2.0 * w * w, a, b);
     easting = 500000.0 + c.k0A * (etap + b);
@@ -381,15 +384,17 @@ GSF_HD void utm_inverse_point(const TmConsts& c, double easting, double northing
     double xip = xi - a, etap = eta - b;
     double sh, chd; sinh_cosh_small(etap, sh, chd);
     double sx, cx; gsf_sincos(xip, sx, cx);
-    double taup = sx / sqrt(sh * sh + cx * cx);
+    double taup = sx * fast_rsqrt(sh * sh + cx * cx);
     double lam = atan2(sh, cx);
     double e2m = 1.0 - c.e * c.e;
-    double tau = taup / e2m;
+    const double ie2m = 1.0 / e2m;
+    double tau = taup * ie2m;
     for (int it = 0; it < 6; ++it) {           // Newton on tau'(tau) (Karney 2011 eqs 19-21); converges in 2-3
-        double t1 = sqrt(1.0 + tau * tau);
-        double sig = tm_sigma(c.e, tau / t1);
-        double tpi = tau * sqrt(1.0 + sig * sig) - sig * t1;
-        double dtau = (taup - tpi) / sqrt(1.0 + tpi * tpi) * (1.0 + e2m * tau * tau) / (e2m * t1);
+        const double ot2 = 1.0 + tau * tau, rt1 = fast_rsqrt(ot2), t1 = ot2 * rt1;          // 1/sqrt(1+tau^2), sqrt(1+tau^2)
+        const double sig = tm_sigma(c.e, tau * rt1);
+        const double os2 = 1.0 + sig * sig;
+        const double tpi = tau * (os2 * fast_rsqrt(os2)) - sig * t1;
+        const double dtau = (taup - tpi) * fast_rsqrt(1.0 + tpi * tpi) * (1.0 + e2m * tau * tau) * (ie2m * rt1);
         tau += dtau;
         if (!(fabs(dtau) > 1e-15 * (1.0 + fabs(tau)))) break;
     }
