@@ -539,7 +539,10 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         Quat qi; Vec3 u;
         if (telescope) {
             const Quat Cq = quat_mul(cq, quat_conj(c_r));
-            qi = is_init ? cq : ekf_normalize(quat_mul(Cq, r));
+            // normalize_quaternion (ref :697-700) is the identity here up to rounding: Cq and r are unit quaternions (every
+            // quaternion of the chunk passed quat_unit), so |Cq r| = 1 +- 2e-16 and its "norm > 1e-9" guard cannot fire.  The
+            // product is written out as it is; the carried cq picks up at most one rounding of the norm per CHUNK.
+            qi = is_init ? cq : quat_mul(Cq, r);
             u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
             u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
         } else {
