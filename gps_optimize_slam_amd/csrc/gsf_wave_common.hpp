@@ -474,7 +474,8 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         Quat r; const bool ok = quat_unit(q, r);
         const double t_pr = prev_lane(c_t, t);
         const Vec3 p_pr{ prev_lane(c_po.x, p.x), prev_lane(c_po.y, p.y), prev_lane(c_po.z, p.z) };
-        const Quat r_pr = prev_lane(c_r, r);
+        // (the previous pose's unit quaternion is only needed on the cold paths -- generic orientation, sharp-turn pairs -- and the
+        // cross-lane move cannot be sunk there by the compiler: it is fetched inside those wave-uniform branches)
         const u64 ok_mask = __ballot(ok);
         const bool ok_pr = (lane == 0) ? c_ok : (((ok_mask >> (lane - 1)) & 1ull) != 0ull);
         const double dt = fmax(1e-6, t - t_pr);                          // ref :865
@@ -487,7 +488,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
         Vec3 dpl{ 0.0, 0.0, 0.0 }; Quat dq{ 0.0, 0.0, 0.0, 1.0 };
         if (!telescope) {                                                // calculate_relative_pose, ref :77-92
-            const Quat r1i = quat_conj(r_pr);
+            const Quat r1i = quat_conj(prev_lane(c_r, r));
             dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
             dq = quat_mul(r1i, r);
             const bool move = stepping && both_ok;
@@ -508,6 +509,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         // is_sharp_turn_in_segment (ref :808-826): pair (i-1, i) exceeds the yaw-rate threshold (or has a bad quaternion)
         u64 f_mask = 0ull;
         if (pair_mask != 0ull) {
+            const Quat r_pr = prev_lane(c_r, r);
             bool f = false;
             if (outpair && t > t_pr) f = !both_ok || yaw_rate_exceeds(r_pr, r, t - t_pr, cfg.yaw_thr_rad);
             f_mask = __ballot(f);
@@ -595,15 +597,14 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
 #undef GSF_ASTAGE_X
 #undef GSF_ASTAGE
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            xl[c] = be[c];                                               // x_i (the carry is x = 0)
-            dcorr[c] = xl[c] - (prev_lane(0.0, be[c]) + uu[c]);          // x_f[i] - x_p[i] (non-zero only where a fix was used)
-        }
+        for (int c = 0; c < 3; ++c) xl[c] = be[c];                      // x_i (the carry is x = 0)
 
         // ---- per-outage RTS (ref :906-922, :777-803).  Inside an outage x_f = x_p and P_f = P_p, so the gain product
         // telescopes: x_s[k] = x_f[k] + (P_f[k] / P_p[r]) (x_f[r] - x_p[r]) for k in [start, r-1], r = the recovery pose.
         double xo[3] = { xl[0], xl[1], xl[2] };                          // what is written out (filter state stays xl)
         if (rts_mask != 0ull) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dcorr[c] = xl[c] - (prev_lane(0.0, be[c]) + uu[c]);   // x_f[i] - x_p[i] (non-zero only where a fix was used)
             const u64 later = rec_mask & ~bits(0, lane);                 // recoveries after this lane
             const int rl = later != 0ull ? __ffsll((long long)later) - 1 : 0;
             const bool in_run = active && !av && later != 0ull && (((rts_mask >> rl) & 1ull) != 0ull);
