@@ -7,8 +7,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw, out = os.path.join(root, "gpurun_out", "profiles_raw"), os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-ks = glob.glob(raw + "/trace_bench_default/**/*_kernel_stats.csv", recursive=True)
-kt = glob.glob(raw + "/trace_bench_default/**/*_kernel_trace.csv", recursive=True)
+ks = sorted(glob.glob(raw + "/trace_bench_default/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)   # newest first: gpurun MERGES runs
+kt = sorted(glob.glob(raw + "/trace_bench_default/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime, reverse=True)
 if ks:
     shutil.copy(ks[0], f"{out}/{tag}_bench_default_kernel_stats.csv")
 if kt:
