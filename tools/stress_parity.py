@@ -1,0 +1,38 @@
+"""One-off large randomised parity sweep (GPU box): every default K4 build against the oracle on tens of thousands of tracks with
+random outage / sharp-turn / NaN-fix patterns (the generator of tests/test_gpu_parity.py).  usage: stress_parity.py [NB] [N] [SEED]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from gps_optimize_slam_amd import batch as B
+from oracle import oracle as orc
+from test_gpu_parity import _random_outage_batch
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 257
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+t0 = time.time()
+ts, pos, quat, gps, valid, ip, iq = _random_outage_batch(nb, N, seed)
+print(f"generated {nb} x {N} in {time.time() - t0:.1f} s", flush=True)
+t0 = time.time()
+po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
+print(f"oracle {time.time() - t0:.1f} s; status histogram {np.bincount(sto, minlength=32)[:16].tolist()}", flush=True)
+worst = 0.0
+for name, layout, opt in (("wave (default)", 0, None), ("lane (time-major)", 1, None), ("block", 0, ("ekf_variant", 8)), ("single-shot", 0, ("seg_kernel", 1))):
+    if opt and opt[0] == "seg_kernel" and N > 320:
+        continue
+    if opt and opt[0] == "ekf_variant" and N > 1024:
+        continue
+    batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
+    if opt: B.context().set_option(*opt)
+    try:
+        p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
+    finally:
+        if opt: B.context().set_option(opt[0], 0)
+    bad = np.nonzero(st != sto)[0]
+    dp, dq = np.abs(p - po).max(), np.abs(q - qo).max()
+    worst = max(worst, dp)
+    print(f"{name:20s} status mismatches {len(bad)} {bad[:5].tolist()}  max|dp| {dp:.3e} m  max|dq| {dq:.3e}", flush=True)
+    assert len(bad) == 0 and dp < 1e-6 and dq < 1e-8
+print("OK, worst position error", worst)
