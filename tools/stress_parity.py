@@ -36,3 +36,25 @@ for name, layout, opt in (("wave (default)", 0, None), ("lane (time-major)", 1, 
     print(f"{name:20s} status mismatches {len(bad)} {bad[:5].tolist()}  max|dp| {dp:.3e} m  max|dq| {dq:.3e}", flush=True)
     assert len(bad) == 0 and dp < 1e-6 and dq < 1e-8
 print("OK, worst position error", worst)
+
+# ---- the fused pipeline (fit on the valid rows -> Sim3 of pose 0 -> filter) against the oracle's, incl. the two-wave kernel's range
+t0 = time.time()
+pr, qr, str_, Rr, tr, sr = orc.fuse_pipeline_batch(ts, pos, quat, gps, valid)
+ok = np.isfinite(pr).all(axis=(1, 2))
+print(f"oracle pipeline {time.time() - t0:.1f} s; {int((~ok).sum())} tracks without a fit", flush=True)
+for name, layout, opt in (("wave pipeline", 0, ("duo_kernel", 0)), ("two-wave pipeline", 0, ("duo_kernel", 1)), ("lane pipeline", 1, None)):
+    if opt and opt[0] == "duo_kernel" and opt[1] == 1 and N > 640:
+        continue
+    batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
+    if opt: B.context().set_option(*opt)
+    try:
+        out, R, t, s = B.fuse_pipeline_batch(batch)
+        p, q, st = out.host_traj_major()
+    finally:
+        if opt: B.context().set_option(opt[0], -1 if opt[0] == "duo_kernel" else 0)
+    assert (np.isfinite(p).all(axis=(1, 2)) == ok).all()
+    bad = np.nonzero((st[ok] & 0xff) != (str_[ok] & 0xff))[0]
+    dp, dq, ds = np.abs(p[ok] - pr[ok]).max(), np.abs(q[ok] - qr[ok]).max(), np.abs(s.cpu().numpy()[ok] - sr[ok]).max()
+    print(f"{name:20s} status mismatches {len(bad)}  max|dp| {dp:.3e} m  max|dq| {dq:.3e}  max|ds| {ds:.3e}", flush=True)
+    assert len(bad) == 0 and dp < 1e-6
+print("pipeline OK")
