@@ -173,7 +173,8 @@ def main():
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     if layout_name == "traj":
-        kernel_name = "ekf_wave_kernel<true>" if args.kernel == "pipeline" else "ekf_wave_kernel<false>"      # <PIPELINE>
+        # <PIPELINE, SMALLBATCH>: up to 2 048 tracks the build with inlined cold blocks is launched (same arithmetic)
+        kernel_name = "ekf_wave_kernel<%s, %s>" % ("true" if args.kernel == "pipeline" else "false", "true" if Bn <= 2048 else "false")
         grid_threads = Bn * 64
     else:
         kernel_name = "fuse_pipeline_kernel" if args.kernel == "pipeline" else "ekf_fuse_kernel"

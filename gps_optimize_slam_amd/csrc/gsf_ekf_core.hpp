@@ -74,6 +74,34 @@ GSF_HD_COLD bool yaw_rate_exceeds(Quat r1, Quat r2, double dt, double thr)   // 
     return cosd < cos(c);
 }
 
+// The same test without a libm call on the usual range (c = thr dt <= pi/4: degree-14 kernel polynomial of cos) -- for the wave
+// kernels, where the cold blocks of a launch start with a cold instruction cache: the call into yaw_rate_exceeds and on into
+// libm's cos costs ~1 us of instruction-fetch misses per wave that meets an outage, and at small batches the slowest wave IS the
+// launch time.  Two wrappers around one body: a CALL for big batches (inlined it costs the hot loop 27 registers, i.e. one wave
+// per SIMD) and an INLINE form for small batches, where registers are free and even the one far call is worth avoiding.
+GSF_HD bool yaw_rate_exceeds_body(const Quat& r1, const Quat& r2, double dt, double thr)
+{
+    double a1, b1, a2, b2;
+    yaw_vec(r1, a1, b1); yaw_vec(r2, a2, b2);
+    double h1 = a1 * a1 + b1 * b1, h2 = a2 * a2 + b2 * b2;
+    if (!(h1 > 0.0)) { a1 = 1.0; b1 = 0.0; h1 = 1.0; }
+    if (!(h2 > 0.0)) { a2 = 1.0; b2 = 0.0; h2 = 1.0; }
+    const double c = thr * dt;
+    const double cosd = (a1 * a2 + b1 * b2) * fast_rsqrt(h1 * h2);
+    double cc;
+    if (c <= 0.785) {
+        const double z = c * c;
+        const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                          z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+        cc = fma(z * z, pc, fma(-0.5, z, 1.0));
+    } else {
+        cc = cos(c);
+    }
+    const bool exceeds = cosd < cc;
+    return (c < 0.0) ? true : ((c < 3.141592653589793) ? exceeds : false);
+}
+GSF_HD_COLD bool yaw_rate_exceeds_poly(Quat r1, Quat r2, double dt, double thr) { return yaw_rate_exceeds_body(r1, r2, dt, thr); }
+
 // Out must provide:
 //   void  store(int64_t i, const Vec3& p, const Quat& q);      fused pose i
 //   void  load(int64_t i, Vec3& p, Quat& q) const;             read back a previously stored pose

@@ -22,10 +22,10 @@ using namespace gsf;
 
 namespace {
 
-template <bool PIPELINE>
+template <bool PIPELINE, bool SMALLBATCH>
 __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
-    wave_serial_body<PIPELINE>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
+    wave_serial_body<PIPELINE, false, SMALLBATCH>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig
         __syncthreads();
         return;
     }
-    wave_serial_body<PIPELINE, true>(a, cfg, b, lane, gsf_pv, pv_stride);
+    wave_serial_body<PIPELINE, true, true>(a, cfg, b, lane, gsf_pv, pv_stride);
 }
 
 // Several poses per lane: an iteration takes 64 * P consecutive poses, P = min(PPLMAX, ceil(remaining / 64)), lane l owning the P
@@ -163,9 +163,14 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     case 3: GSF_LAUNCH_WAVEP(3); break;
     case 4: GSF_LAUNCH_WAVEP(4); break;
     case 5: GSF_LAUNCH_WAVEP(5); break;
-    default:
-        if (pipeline) hipLaunchKernelGGL(ekf_wave_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-        else hipLaunchKernelGGL(ekf_wave_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+    default: {
+        // up to 2 048 waves (two per SIMD) the build with inlined cold blocks costs no occupancy; same arithmetic, same bits
+        const bool small = B <= 2048;
+        if (pipeline) { if (small) hipLaunchKernelGGL((ekf_wave_kernel<true, true>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+                        else hipLaunchKernelGGL((ekf_wave_kernel<true, false>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); }
+        else { if (small) hipLaunchKernelGGL((ekf_wave_kernel<false, true>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
+               else hipLaunchKernelGGL((ekf_wave_kernel<false, false>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); }
+    }
     }
 #undef GSF_LAUNCH_WAVEP
     GSF_HIP(hipGetLastError());

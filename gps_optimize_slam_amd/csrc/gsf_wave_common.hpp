@@ -158,7 +158,15 @@ __device__ __forceinline__ void traj_span(const WaveArgs& a, int64_t b, int64_t&
 #ifdef GSF_CHUNK_TIMING
 // diagnostic build only (tools/chunk_timing.py): wave 0 writes (shader clock, 100 MHz clock) stamps into status[2k], status[2k+1];
 // no wave writes its real status word in this build
-#define GSF_STAMP(k) do { if (b == 0 && lane == 0 && a.status) { a.status[2 * (k)] = (int32_t)(clock64() & 0x7fffffff); a.status[2 * (k) + 1] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#ifndef GSF_TIMING_B
+#define GSF_TIMING_B 0
+#endif
+#define GSF_STAMP(k) do { if (b == GSF_TIMING_B && lane == 0 && a.status) { a.status[2 * (k)] = (int32_t)(clock64() & 0x7fffffff); a.status[2 * (k) + 1] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#define GSF_STATUS_PTR(a) ((int32_t*)nullptr)
+#elif defined(GSF_WAVE_START_TIMING)
+// diagnostic build only (tools/wave_start_timing.py): EVERY wave writes the 100 MHz clock at its entry (stamp 0) and at its last
+// chunk (stamp 8 + last chunk) into status[b] / status[B + b]; no real status words in this build
+#define GSF_STAMP(k) do { if (lane == 0 && a.status) { if ((k) == 0) a.status[b] = (int32_t)(wall_clock64() & 0x7fffffff); else if ((k) >= 8) a.status[a.B + b] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
 #define GSF_STATUS_PTR(a) ((int32_t*)nullptr)
 #else
 #define GSF_STAMP(k) do { } while (0)
@@ -412,7 +420,8 @@ __device__ __forceinline__ void wave_variance_helper(const WaveArgs& a, const Ek
 // One wave walks trajectory `b` 64 poses at a time (serial over chunks, scans inside a chunk).
 // PREVAR (two-wave kernel): the variances come from LDS (pv, written by wave_variance_helper) once the block barrier after the
 // fit has been passed; everything else is identical, so the two kernels produce the same bits.
-template <bool PIPELINE, bool PREVAR = false>
+// SMALLBATCH: the cold blocks are inlined (no far calls; ~27 more registers, which only matter when three waves per SIMD do).
+template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false>
 __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
                                                  const double* pv = nullptr, const int pv_stride = 0)
 {
@@ -427,6 +436,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
 
+    __shared__ double gsf_ring[2][6][64];                                // lane-private: rows + P_f of the last two open-outage chunks
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
     ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     Vec3 p0; Quat q0; int32_t fit = 0;
@@ -511,7 +521,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         if (pair_mask != 0ull) {
             const Quat r_pr = prev_lane(c_r, r);
             bool f = false;
-            if (outpair && t > t_pr) f = !both_ok || yaw_rate_exceeds(r_pr, r, t - t_pr, cfg.yaw_thr_rad);
+            if (outpair && t > t_pr) f = !both_ok || (SMALLBATCH ? yaw_rate_exceeds_body(r_pr, r, t - t_pr, cfg.yaw_thr_rad) : yaw_rate_exceeds_poly(r_pr, r, t - t_pr, cfg.yaw_thr_rad));
             f_mask = __ballot(f);
         }
         // recovery decision per recovering lane (ref :879-894)
@@ -619,8 +629,12 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
                 if ((rts_mask >> r1) & 1ull) {
                     const double dr[3] = { lane_bcast(dcorr[0], r1), lane_bcast(dcorr[1], r1), lane_bcast(dcorr[2], r1) };
                     const double ipr[3] = { fast_rcp(lane_bcast(Pm[0], r1)), fast_rcp(lane_bcast(Pm[1], r1)), fast_rcp(lane_bcast(Pm[2], r1)) };
+                    // The last two chunks of the run are patched from a lane-private LDS ring (the rows as they were written and
+                    // their P_f, kept by every chunk that ended inside the outage): no global read-modify-write, no stamps to
+                    // re-scan.  Only a run that reaches further back than 128 poses takes the memory path for its older chunks.
+                    const int64_t kfirst = (c_ostart / 64) * 64, kring = (c0 - 128 > kfirst) ? c0 - 128 : kfirst;
                     double acc = 0.0;                                    // sum of dt over (ostart, k]
-                    for (int64_t k0 = (c_ostart / 64) * 64; k0 < c0; k0 += 64) {
+                    for (int64_t k0 = kfirst; k0 < kring; k0 += 64) {
                         const int64_t k = k0 + lane;
                         const double tk = tsb[k];
                         const double tkp = prev_lane((k0 > 0) ? tsb[k0 - 1] : tk, tk);
@@ -638,6 +652,15 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
                         }
                         acc += tot;
                     }
+                    for (int64_t k0 = kring; k0 < c0; k0 += 64) {
+                        const int64_t k = k0 + lane;
+                        const int slot = (int)(k0 >> 6) & 1;
+                        if (k >= c_ostart) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                __builtin_nontemporal_store(gsf_ring[slot][c][lane] + gsf_ring[slot][3 + c][lane] * ipr[c] * dr[c], &pob[k * 3 + c]);
+                        }
+                    }
                 }
             }
         }
@@ -648,6 +671,10 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         // ---- carry to the next 64 poses (from the last active lane L)
         const bool open = ((a_mask >> L) & 1ull) == 0ull;                // the chunk ends inside an outage
         if (open) {
+            // keep this chunk's rows and variances for the recovery that will smooth them (see the per-outage RTS above)
+            { const int slot = (int)(c0 >> 6) & 1;
+              gsf_ring[slot][0][lane] = o0; gsf_ring[slot][1][lane] = o1; gsf_ring[slot][2][lane] = o2;
+              gsf_ring[slot][3][lane] = Pf[0]; gsf_ring[slot][4][lane] = Pf[1]; gsf_ring[slot][5][lane] = Pf[2]; }
             const u64 sm = start_mask & bits(0, L);
             if (sm != 0ull) {
                 const int s = 63 - __clzll((long long)sm);

@@ -16,7 +16,7 @@ if kt:
 if os.path.exists(raw + "/bench_default.json"):
     shutil.copy(raw + "/bench_default.json", f"{out}/{tag}_bench_default_under_rocprof.json")
 traffic = {}
-pat = re.compile(r"(ekf_wave_kernel<\w+>|fuse_pipeline_kernel|ekf_fuse_kernel)")
+pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel)")
 for wl in ("c2", "c3"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{raw}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
