@@ -235,7 +235,12 @@ __device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const 
     const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - dst[r * 3];
     const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - dst[r * 3 + 1];
     const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - dst[r * 3 + 2];
-    return sqrt(dx * dx + dy * dy + dz * dz) < thr;                           // ref :410-411
+    // ref :410-411 tests norm < thr, i.e. sqrt(d2) < thr.  The correctly rounded sqrt is only needed within a few ulp of the
+    // boundary: d2 clearly below / above thr^2 decides without it (the band is ~50x wider than the rounding of d2 and thr^2).
+    const double d2 = dx * dx + dy * dy + dz * dz, t2 = thr * thr;
+    if (d2 < t2 * (1.0 - 1e-14)) return thr > 0.0;
+    if (!(d2 <= t2 * (1.0 + 1e-14))) return false;                          // also NaN -> false, like the comparison with sqrt(NaN)
+    return sqrt(d2) < thr;
 }
 
 __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
