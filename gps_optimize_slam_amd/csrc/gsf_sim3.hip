@@ -228,19 +228,29 @@ __device__ __forceinline__ int32_t fit_sample(const double* __restrict__ src, co
     return umeyama_finalize(H, ssq, sc, dc, n, R, t, s);
 }
 
-__device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
-                                          const double* R, const double* t, double s, double thr)
+// squared residual of row r under (R, t, s): pure arithmetic, so that several rows' loads can be in flight together
+__device__ __forceinline__ double resid2(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
+                                         const double* R, const double* t, double s)
 {
     const double x = src[r * 3], y = src[r * 3 + 1], z = src[r * 3 + 2];
     const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - dst[r * 3];
     const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - dst[r * 3 + 1];
     const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - dst[r * 3 + 2];
-    // ref :410-411 tests norm < thr, i.e. sqrt(d2) < thr.  The correctly rounded sqrt is only needed within a few ulp of the
-    // boundary: d2 clearly below / above thr^2 decides without it (the band is ~50x wider than the rounding of d2 and thr^2).
-    const double d2 = dx * dx + dy * dy + dz * dz, t2 = thr * thr;
+    return dx * dx + dy * dy + dz * dz;
+}
+// ref :410-411 tests norm < thr, i.e. sqrt(d2) < thr.  The correctly rounded sqrt is only needed within a few ulp of the boundary:
+// d2 clearly below / above thr^2 decides without it (the band is ~50x wider than the rounding of d2 and thr^2).
+__device__ __forceinline__ bool within(double d2, double thr)
+{
+    const double t2 = thr * thr;
     if (d2 < t2 * (1.0 - 1e-14)) return thr > 0.0;
     if (!(d2 <= t2 * (1.0 + 1e-14))) return false;                          // also NaN -> false, like the comparison with sqrt(NaN)
     return sqrt(d2) < thr;
+}
+__device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
+                                          const double* R, const double* t, double s, double thr)
+{
+    return within(resid2(src, dst, r, R, t, s), thr);
 }
 
 __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
@@ -275,7 +285,17 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
         double R[9], t[3], s;
         if (fit_sample(src, dst, i0, my_idx + (size_t)tr * ms, ms, R, t, s) == SIM3_NONE) continue;   // :408
         long long cnt = 0;
-        for (int64_t r = i0; r < i1; ++r) cnt += is_inlier(src, dst, r, R, t, s, thr) ? 1 : 0;
+        // the rows are wave-uniform scalar loads: eight rows' residuals are formed before the first decision so that their loads are
+        // in flight together (one row per round trip otherwise: the loop was latency-bound)
+        int64_t r = i0;
+        for (; r + 8 <= i1; r += 8) {
+            double d2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d2[u] = resid2(src, dst, r + u, R, t, s);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += within(d2[u], thr) ? 1 : 0;
+        }
+        for (; r < i1; ++r) cnt += is_inlier(src, dst, r, R, t, s, thr) ? 1 : 0;
         if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
     }
     // block arg-max: highest count, then lowest trial index
