@@ -112,6 +112,7 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
         m = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + tau) * ms, ms, degree);
         // |y - y_pred| <= threshold over all rows (ref loss "absolute_error"), then r2_score of the model on its inliers
         int cnt = 0; double sy = 0.0;
+#pragma unroll 8                                                          // rows are wave-uniform scalar loads: keep several in flight
         for (int i = 0; i < n; ++i) {
             const double res = fabs(yp[i] - poly_predict(m, degree, tp[i]));
             if (res <= thr) { ++cnt; sy += yp[i]; }
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
         if (cnt >= 2) {
             const double ym = sy / (double)cnt;
             double ss_res = 0.0, ss_tot = 0.0;
+#pragma unroll 8
             for (int i = 0; i < n; ++i) {
                 const double pr = poly_predict(m, degree, tp[i]);
                 if (fabs(yp[i] - pr) <= thr) { ss_res += (yp[i] - pr) * (yp[i] - pr); ss_tot += (yp[i] - ym) * (yp[i] - ym); }
