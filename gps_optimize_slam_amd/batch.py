@@ -239,3 +239,13 @@ def ransac_poly_batch(t, y, offsets, sample_idx, degree, residual_threshold, sto
     check(_lib.load().gsf_ransac_poly_batch_dev(context().handle, _p(t), _p(y), _p(offsets), P, _p(sample_idx), trials, ms, int(degree),
                                                 float(residual_threshold), float(stop_probability), _p(mask), _p(ntr), _p(nin), _p(st)))
     return mask, ntr, nin, st
+
+
+def eval_errors_batch(ts, traj_pos, gps, valid, skip_seconds=0.0):
+    """next-4 over device tensors (trajectory-major (B,N) / (B,N,3)): nearest-fix error of every fused pose (ref :1013-1033).
+    Returns stats (B,4) = count, mean, median, RMSE and errors (B,N) (NaN where not evaluated)."""
+    Bn, N = ts.shape
+    stats = torch.empty((Bn, 4), dtype=torch.float64, device=ts.device)
+    err = torch.empty((Bn, N), dtype=torch.float64, device=ts.device)
+    check(_lib.load().gsf_eval_errors_batch_dev(context().handle, _p(ts), _p(traj_pos), _p(gps), _p(valid), Bn, N, float(skip_seconds), _p(stats), _p(err)))
+    return stats, err

@@ -41,10 +41,12 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
         if (in_set(i)) {
             const double x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
             double best = INFINITY;
+            // the candidate rows are wave-uniform scalar loads: branch-free and unrolled so that several are in flight at once
+#pragma unroll 8
             for (int64_t j = 0; j < N; ++j) {                            // :1030-1031
-                if (!in_set(j)) continue;
                 const double dx = x - g[j * 3], dy = y - g[j * 3 + 1], dz = z - g[j * 3 + 2];
-                best = fmin(best, dx * dx + dy * dy + dz * dz);
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                best = fmin(best, in_set(j) ? d2 : INFINITY);
             }
             err = sqrt(best);
             cnt += 1.0; sum += err; sum2 += err * err;
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
             const double ei = e[i];
             if (isnan(ei)) continue;
             int64_t rank = 0;
+#pragma unroll 8
             for (int64_t j = 0; j < N; ++j) { const double ej = e[j]; rank += (ej < ei || (ej == ei && j < i)) ? 1 : 0; }
             if (rank == k_lo) sh_med[0] = ei;
             if (rank == k_hi) sh_med[1] = ei;

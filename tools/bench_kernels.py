@@ -80,4 +80,12 @@ idx = torch.argsort(torch.rand(P, trials, n, device=dev, generator=g), dim=2)[:,
 ms_t = timed(lambda: B.ransac_poly_batch(t, y, offs, idx, 2, 10.0))
 out["next3_ransac_poly_30k_problems_150rows_50trials"] = {"ms": ms_t, "problems_per_s": P / ms_t * 1e3, "residual_evals_per_s": P * trials * n * 2 / ms_t * 1e3}
 del t, y, offs, idx, spike
+# ---- next-4: error evaluation (nearest-fix distances, mean / median / RMSE) on 1 000 fused 271-pose tracks
+bt = B.TrajectoryBatch.synthetic(1000, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
+fo = B.ekf_fuse_batch(bt)
+try:
+    ms_e = timed(lambda: B.eval_errors_batch(bt.ts, fo.pos, bt.gps, bt.valid, 0.0))
+    out["next4_eval_errors_1000traj_271"] = {"ms": ms_e, "Mpairs_s": 1000 * 271 * 271 / ms_e / 1e3}
+except Exception as ex:                                                  # signature differences must not hide the other timings
+    out["next4_eval_errors_1000traj_271"] = {"error": str(ex)}
 print(json.dumps(out, indent=1))
