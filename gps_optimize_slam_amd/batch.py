@@ -94,12 +94,21 @@ class TrajectoryBatch:
 
 
 class FusedPoses:
-    def __init__(self, layout, B, N, device="cuda"):
+    """Fused poses of a batch.  pos and quat are views of ONE allocation `buf` = [pos | quat] (7 doubles per pose), so the
+    multi-GPU collect is a single all-gather of `buf`.  `buf` may be a caller-provided slice of a larger arena."""
+
+    def __init__(self, layout, B, N, device="cuda", buf=None):
         _, s_pos, s_quat, _, _ = shapes(layout, B, N)
         self.layout, self.B, self.N = layout, B, N
-        self.pos = torch.empty(s_pos, dtype=torch.float64, device=device)
-        self.quat = torch.empty(s_quat, dtype=torch.float64, device=device)
-        self.status = torch.empty((B,), dtype=torch.int32, device=device)
+        P = B * N
+        if buf is None:
+            buf = torch.empty((P * 7,), dtype=torch.float64, device=device)
+        elif buf.dtype != torch.float64 or buf.numel() != P * 7 or not buf.is_contiguous():
+            raise ValueError(f"FusedPoses: buf must be a contiguous float64 tensor of {P * 7} elements")
+        self.buf = buf.view(-1)
+        self.pos = self.buf[: P * 3].view(s_pos)
+        self.quat = self.buf[P * 3:].view(s_quat)
+        self.status = torch.empty((B,), dtype=torch.int32, device=self.buf.device)
 
     def host_traj_major(self):
         """-> (pos (B,N,3), quat (B,N,4), status (B,)) numpy"""

@@ -167,12 +167,6 @@ __global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double*
     }
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
 }  // namespace
 
 extern "C" {
@@ -206,28 +200,20 @@ int gsf_time_align_batch(gsf_ctx* ctx, const double* slam_t, const int64_t* slam
 {
     GSF_REQUIRE(ctx && slam_offsets && gps_offsets && B >= 0, "bad arguments");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
     const int64_t ns = slam_offsets[B], ng = gps_offsets[B];
     GSF_REQUIRE(ns >= 0 && ng >= 0 && (ns == 0 || (slam_t && aligned && valid)) && (ng == 0 || (gps_t && gps_p)), "bad offsets / NULL arrays");
     int64_t maxg = 2;
     for (int64_t b = 0; b < B; ++b) { const int64_t g = gps_offsets[b + 1] - gps_offsets[b]; if (g > maxg) maxg = g; }
-    DevBuf d;
-    GSF_HIP(d.alloc((size_t)ns * (8 + 24 + 1) + (size_t)ng * 32 + (size_t)(B + 1) * 16 + (size_t)B * 4 + 64));
-    double* dst = (double*)d.p; double* dal = dst + ns; double* dgt = dal + 3 * ns; double* dgp = dgt + ng;
-    int64_t* dso = (int64_t*)(dgp + 3 * ng); int64_t* dgo = dso + (B + 1); int32_t* dstat = (int32_t*)(dgo + (B + 1)); uint8_t* dva = (uint8_t*)(dstat + B);
-#define H2D(dst_, src_, bytes) GSF_HIP(hipMemcpyAsync((dst_), (src_), (bytes), hipMemcpyHostToDevice, ctx->stream))
-#define D2H(dst_, src_, bytes) GSF_HIP(hipMemcpyAsync((dst_), (src_), (bytes), hipMemcpyDeviceToHost, ctx->stream))
-    if (ns) H2D(dst, slam_t, (size_t)ns * 8);
-    if (ng) { H2D(dgt, gps_t, (size_t)ng * 8); H2D(dgp, gps_p, (size_t)ng * 24); }
-    H2D(dso, slam_offsets, (size_t)(B + 1) * 8); H2D(dgo, gps_offsets, (size_t)(B + 1) * 8);
-    int rc = gsf_time_align_batch_dev(ctx, dst, dso, dgt, dgp, dgo, B, (int32_t)maxg, max_gps_gap_threshold, dal, dva, dstat);
+    Staging st(ctx, (size_t)ns * 33 + (size_t)ng * 32 + (size_t)(B + 1) * 16 + (size_t)B * 4, 8);
+    if (st.rc()) return st.rc();
+    const double* dst = st.in(slam_t, (size_t)ns); const double* dgt = st.in(gps_t, (size_t)ng); const double* dgp = st.in(gps_p, (size_t)ng * 3);
+    const int64_t* dso = st.in(slam_offsets, (size_t)B + 1); const int64_t* dgo = st.in(gps_offsets, (size_t)B + 1);
+    double* dal = st.out(aligned, (size_t)ns * 3); uint8_t* dva = st.out(valid, (size_t)ns); int32_t* dstat = st.out(status, (size_t)B);
+    int rc = st.upload();
     if (rc) return rc;
-    if (ns) { D2H(aligned, dal, (size_t)ns * 24); D2H(valid, dva, (size_t)ns); }
-    if (status) D2H(status, dstat, (size_t)B * 4);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-#undef H2D
-#undef D2H
-    return GSF_OK;
+    rc = gsf_time_align_batch_dev(ctx, dst, dso, dgt, dgp, dgo, B, (int32_t)maxg, max_gps_gap_threshold, dal, dva, dstat);
+    if (rc) return rc;
+    return st.finish();
 }
 
 }  // extern "C"

@@ -253,16 +253,10 @@ __global__ void rts_segment_kernel(const double* xf, const double* Pf, const dou
     }
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
 }  // namespace
 
-#define H2D(dst, src, bytes) GSF_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
-#define D2H(dst, src, bytes) GSF_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->stream))
+#define ST_BEGIN(bytes, n) Staging st(ctx, (bytes), (n)); if (st.rc()) return st.rc()
+#define ST_UPLOAD() do { int rc__ = st.upload(); if (rc__) return rc__; } while (0)
 
 extern "C" {
 
@@ -271,32 +265,27 @@ int gsf_relative_pose_batch(gsf_ctx* ctx, const double* p1, const double* q1, co
 {
     GSF_REQUIRE(ctx && n >= 0 && (n == 0 || (p1 && q1 && p2 && q2 && dp && dq)), "bad arguments");
     if (n == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    DevBuf d; GSF_HIP(d.alloc((size_t)n * (21 * 8 + 4)));
-    double* a = (double*)d.p; double* dq1 = a + 3 * n; double* dp2 = dq1 + 4 * n; double* dq2 = dp2 + 3 * n; double* ddp = dq2 + 4 * n; double* ddq = ddp + 3 * n;
-    int32_t* dbad = (int32_t*)(ddq + 4 * n);
-    H2D(a, p1, (size_t)n * 24); H2D(dq1, q1, (size_t)n * 32); H2D(dp2, p2, (size_t)n * 24); H2D(dq2, q2, (size_t)n * 32);
+    ST_BEGIN((size_t)n * (21 * 8 + 4), 7);
+    const double* a = st.in(p1, (size_t)n * 3); const double* dq1 = st.in(q1, (size_t)n * 4);
+    const double* dp2 = st.in(p2, (size_t)n * 3); const double* dq2 = st.in(q2, (size_t)n * 4);
+    double* ddp = st.out(dp, (size_t)n * 3); double* ddq = st.out(dq, (size_t)n * 4); int32_t* dbad = st.out(bad, (size_t)n);
+    ST_UPLOAD();
     hipLaunchKernelGGL(relative_pose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, dq1, dp2, dq2, n, ddp, ddq, dbad);
     GSF_HIP(hipGetLastError());
-    D2H(dp, ddp, (size_t)n * 24); D2H(dq, ddq, (size_t)n * 32);
-    if (bad) D2H(bad, dbad, (size_t)n * 4);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return st.finish();
 }
 
 int gsf_quaternion_nlerp_batch(gsf_ctx* ctx, const double* q1, const double* q2, const double* w, int64_t n, double* out)
 {
     GSF_REQUIRE(ctx && n >= 0 && (n == 0 || (q1 && q2 && w && out)), "bad arguments");
     if (n == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    DevBuf d; GSF_HIP(d.alloc((size_t)n * 13 * 8));
-    double* a = (double*)d.p; double* b = a + 4 * n; double* dw = b + 4 * n; double* o = dw + n;
-    H2D(a, q1, (size_t)n * 32); H2D(b, q2, (size_t)n * 32); H2D(dw, w, (size_t)n * 8);
+    ST_BEGIN((size_t)n * 13 * 8, 4);
+    const double* a = st.in(q1, (size_t)n * 4); const double* b = st.in(q2, (size_t)n * 4); const double* dw = st.in(w, (size_t)n);
+    double* o = st.out(out, (size_t)n * 4);
+    ST_UPLOAD();
     hipLaunchKernelGGL(nlerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, dw, n, o);
     GSF_HIP(hipGetLastError());
-    D2H(out, o, (size_t)n * 32);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return st.finish();
 }
 
 int gsf_is_sharp_turn_batch(gsf_ctx* ctx, const double* quats, const double* stamps, const int64_t* offsets, int64_t B,
@@ -304,20 +293,17 @@ int gsf_is_sharp_turn_batch(gsf_ctx* ctx, const double* quats, const double* sta
 {
     GSF_REQUIRE(ctx && offsets && result && B >= 0 && B <= 0x7fffffff, "bad arguments");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
     const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (quats && stamps)), "bad offsets / NULL arrays");
-    DevBuf d; GSF_HIP(d.alloc((size_t)total * 5 * 8 + (size_t)(B + 1) * 8 + (size_t)B * 12));
-    double* dq = (double*)d.p; double* dt = dq + 4 * total; int64_t* doff = (int64_t*)(dt + total); double* dmr = (double*)(doff + B + 1);
-    int32_t* dres = (int32_t*)(dmr + B);
-    if (total) { H2D(dq, quats, (size_t)total * 32); H2D(dt, stamps, (size_t)total * 8); }
-    H2D(doff, offsets, (size_t)(B + 1) * 8);
+    ST_BEGIN((size_t)total * 5 * 8 + (size_t)(B + 1) * 8 + (size_t)B * 12, 5);
+    const double* dq = st.in(quats, (size_t)total * 4); const double* dt = st.in(stamps, (size_t)total);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    int32_t* dres = st.out(result, (size_t)B);
+    double* dmr = max_rate ? st.out(max_rate, (size_t)B) : st.tmp<double>((size_t)B);
+    ST_UPLOAD();
     hipLaunchKernelGGL(sharp_turn_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, dq, dt, doff, yaw_rate_threshold_rad_per_sec, dres, dmr);
     GSF_HIP(hipGetLastError());
-    D2H(result, dres, (size_t)B * 4);
-    if (max_rate) D2H(max_rate, dmr, (size_t)B * 8);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return st.finish();
 }
 
 int gsf_ekf_process_step(gsf_ctx* ctx, double* state, double* cov, const double* process_noise_per_sec, const double* meas_noise,
@@ -327,20 +313,22 @@ int gsf_ekf_process_step(gsf_ctx* ctx, double* state, double* cov, const double*
 {
     GSF_REQUIRE(ctx && state && cov && process_noise_per_sec && meas_noise && gnss_available_prev && gnss_update_weight && delta_pos_local &&
                 delta_quat && pred_state && pred_cov, "NULL argument");
-    GSF_HIP(hipSetDevice(ctx->device));
     StepIO h;
     memcpy(h.state, state, sizeof h.state); memcpy(h.cov, cov, sizeof h.cov);
     memcpy(h.Qps, process_noise_per_sec, sizeof h.Qps); memcpy(h.R, meas_noise, sizeof h.R);
     h.gnss_prev = *gnss_available_prev; h.weight = *gnss_update_weight; h.current_steps = current_transition_steps;
-    DevBuf d; GSF_HIP(d.alloc(sizeof(StepIO) + (3 + 4 + 3 + 7 + 49) * 8));
-    StepIO* dio = (StepIO*)d.p; double* ddp = (double*)(dio + 1); double* ddq = ddp + 3; double* dz = ddq + 4; double* dps = dz + 3; double* dpc = dps + 7;
-    double znan[3] = { NAN, NAN, NAN };
-    H2D(dio, &h, sizeof h); H2D(ddp, delta_pos_local, 24); H2D(ddq, delta_quat, 32); H2D(dz, gps_meas ? gps_meas : znan, 24);
+    ST_BEGIN(2 * sizeof(StepIO) + (3 + 4 + 3 + 7 + 49) * 8, 8);
+    const double znan[3] = { NAN, NAN, NAN };
+    const StepIO* din = st.in(&h, 1);
+    const double* ddp = st.in(delta_pos_local, 3); const double* ddq = st.in(delta_quat, 4); const double* dz = st.in(gps_meas ? gps_meas : znan, 3);
+    StepIO* dio = st.out(&h, 1); double* dps = st.out(pred_state, 7); double* dpc = st.out(pred_cov, 49);
+    ST_UPLOAD();
+    GSF_HIP(hipMemcpyAsync(dio, din, sizeof(StepIO), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(process_step_kernel, dim3(1), dim3(64), 0, ctx->stream, dio, ddp, ddq, dz, gps_meas ? 1 : 0, gnss_is_available ? 1 : 0,
                        delta_time, override_transition_steps, dps, dpc);
     GSF_HIP(hipGetLastError());
-    D2H(&h, dio, sizeof h); D2H(pred_state, dps, 56); D2H(pred_cov, dpc, 392);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = st.finish();
+    if (rc) return rc;
     memcpy(state, h.state, sizeof h.state); memcpy(cov, h.cov, sizeof h.cov);
     *gnss_available_prev = h.gnss_prev; *gnss_update_weight = h.weight;
     return GSF_OK;
@@ -351,20 +339,18 @@ int gsf_rts_smoother_segment_batch(gsf_ctx* ctx, const double* states_filt, cons
 {
     GSF_REQUIRE(ctx && offsets && B >= 0, "bad arguments");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
     const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (states_filt && covs_filt && states_pred && covs_pred && states_smooth && covs_smooth)), "NULL arrays");
     if (total == 0) return GSF_OK;
-    DevBuf d; GSF_HIP(d.alloc((size_t)total * (3 * 7 + 3 * 49) * 8 + (size_t)(B + 1) * 8));
-    double* xf = (double*)d.p; double* xp = xf + 7 * total; double* xs = xp + 7 * total; double* Pf = xs + 7 * total; double* Pp = Pf + 49 * total;
-    double* Ps = Pp + 49 * total; int64_t* doff = (int64_t*)(Ps + 49 * total);
-    H2D(xf, states_filt, (size_t)total * 56); H2D(xp, states_pred, (size_t)total * 56); H2D(Pf, covs_filt, (size_t)total * 392);
-    H2D(Pp, covs_pred, (size_t)total * 392); H2D(doff, offsets, (size_t)(B + 1) * 8);
+    ST_BEGIN((size_t)total * (3 * 7 + 3 * 49) * 8 + (size_t)(B + 1) * 8, 7);
+    const double* xf = st.in(states_filt, (size_t)total * 7); const double* xp = st.in(states_pred, (size_t)total * 7);
+    const double* Pf = st.in(covs_filt, (size_t)total * 49); const double* Pp = st.in(covs_pred, (size_t)total * 49);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    double* xs = st.out(states_smooth, (size_t)total * 7); double* Ps = st.out(covs_smooth, (size_t)total * 49);
+    ST_UPLOAD();
     hipLaunchKernelGGL(rts_segment_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, xf, Pf, xp, Pp, doff, B, xs, Ps);
     GSF_HIP(hipGetLastError());
-    D2H(states_smooth, xs, (size_t)total * 56); D2H(covs_smooth, Ps, (size_t)total * 392);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return st.finish();
 }
 
 }  // extern "C"

@@ -38,13 +38,93 @@ int ensure_scratch(gsf_ctx* ctx, size_t bytes)
     return GSF_OK;
 }
 
-// RAII device staging for the host-pointer entry points
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    template <class T> T* as() { return (T*)p; }
-};
+static int ensure_arena(void** p, size_t* have, size_t bytes, bool pinned, hipStream_t stream)
+{
+    if (*have >= bytes) return GSF_OK;
+    if (*p) {
+        GSF_HIP(hipStreamSynchronize(stream));
+        GSF_HIP(pinned ? hipHostFree(*p) : hipFree(*p));
+        *p = nullptr; *have = 0;
+    }
+    size_t want = bytes + bytes / 2;                                      // grow-only with headroom: repeated calls stop allocating
+    if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+    hipError_t e = pinned ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want);
+    if (e != hipSuccess && want != bytes) { want = bytes; e = pinned ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want); }
+    if (e != hipSuccess) { *p = nullptr; return fail_hip(e, pinned ? "hipHostMalloc(staging)" : "hipMalloc(staging)"); }
+    *have = want;
+    return GSF_OK;
+}
+
+Staging::Staging(gsf_ctx* ctx, size_t payload_bytes, int n_arrays) : ctx_(ctx)
+{
+    cap_ = payload_bytes + (size_t)256 * (size_t)(n_arrays + 1);
+    direct_ = cap_ > PINNED_MAX;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { rc_ = fail_hip(e, "hipSetDevice"); return; }
+    rc_ = ensure_arena(&ctx->stage, &ctx->stage_bytes, cap_, false, ctx->stream);
+    if (rc_ == GSF_OK && !direct_) rc_ = ensure_arena(&ctx->pinned, &ctx->pinned_bytes, cap_, true, ctx->stream);
+    d_ = (char*)ctx->stage; h_ = (char*)ctx->pinned;
+}
+
+void* Staging::take(size_t bytes, size_t& at)
+{
+    at = (off_ + 255) & ~(size_t)255;
+    if (rc_ != GSF_OK || at + bytes > cap_) {
+        if (rc_ == GSF_OK) { set_error("staging arena overrun (internal sizing error)"); rc_ = GSF_ERR_INVALID_ARG; }
+        return nullptr;
+    }
+    off_ = at + bytes;
+    return d_ + at;
+}
+
+void* Staging::in_bytes(const void* host, size_t bytes)
+{
+    size_t at; void* p = take(bytes, at);
+    if (!p) return nullptr;
+    if (has_out_) { set_error("staging: in() after out()"); rc_ = GSF_ERR_INVALID_ARG; return nullptr; }
+    if (bytes && host) {
+        if (direct_) { hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx_->stream); if (e != hipSuccess) rc_ = fail_hip(e, "hipMemcpyAsync(H2D)"); }
+        else memcpy(h_ + at, host, bytes);
+    }
+    in_end_ = off_;
+    return p;
+}
+
+void* Staging::out_bytes(void* host, size_t bytes)
+{
+    size_t at; void* p = take(bytes, at);
+    if (!p) return nullptr;
+    if (!has_out_) { has_out_ = true; out_lo_ = at; }
+    if (host && bytes) {
+        if (n_out_ >= MAX_OUT) { set_error("staging: too many outputs"); rc_ = GSF_ERR_INVALID_ARG; return nullptr; }
+        outs_[n_out_++] = Out{ host, at, bytes };
+    }
+    return p;
+}
+
+int Staging::upload()
+{
+    if (rc_ != GSF_OK) return rc_;
+    if (!direct_ && in_end_) GSF_HIP(hipMemcpyAsync(d_, h_, in_end_, hipMemcpyHostToDevice, ctx_->stream));
+    return GSF_OK;
+}
+
+int Staging::finish()
+{
+    if (rc_ != GSF_OK) return rc_;
+    if (direct_) {
+        for (int k = 0; k < n_out_; ++k) GSF_HIP(hipMemcpyAsync(outs_[k].host, d_ + outs_[k].off, outs_[k].bytes, hipMemcpyDeviceToHost, ctx_->stream));
+        GSF_HIP(hipStreamSynchronize(ctx_->stream));
+        return GSF_OK;
+    }
+    if (n_out_) {
+        const size_t hi = outs_[n_out_ - 1].off + outs_[n_out_ - 1].bytes;
+        GSF_HIP(hipMemcpyAsync(h_ + out_lo_, d_ + out_lo_, hi - out_lo_, hipMemcpyDeviceToHost, ctx_->stream));
+    }
+    GSF_HIP(hipStreamSynchronize(ctx_->stream));
+    for (int k = 0; k < n_out_; ++k) memcpy(outs_[k].host, h_ + outs_[k].off, outs_[k].bytes);
+    return GSF_OK;
+}
 
 }  // namespace gsf
 
@@ -81,7 +161,8 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     if (device_id < 0 || device_id >= n) { set_error("gsf_create: device %d out of range [0,%d)", device_id, n); return GSF_ERR_INVALID_ARG; }
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
-    c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->ekf_variant = 0; c->wave_ppl = 0; c->seg_kernel = 0; c->duo_kernel = -1;
+    c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
+    c->ekf_variant = 0; c->duo_kernel = -1; c->lane_min_traj = 32768;
     if (owns) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail_hip(e, "hipStreamCreateWithFlags"); }
@@ -102,6 +183,8 @@ void gsf_destroy(gsf_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -123,13 +206,9 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
         if (value < -1 || value > 1) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 or 1"); return GSF_ERR_INVALID_ARG; }
         ctx->duo_kernel = (int)value; return GSF_OK;
     }
-    if (strcmp(key, "seg_kernel") == 0) {
-        if (value < 0 || value > 1) { set_error("gsf_set_option: seg_kernel must be 0 or 1"); return GSF_ERR_INVALID_ARG; }
-        ctx->seg_kernel = (int)value; return GSF_OK;
-    }
-    if (strcmp(key, "wave_ppl") == 0) {
-        if (value < 0 || value > 5) { set_error("gsf_set_option: wave_ppl must be 0 (automatic) .. 5"); return GSF_ERR_INVALID_ARG; }
-        ctx->wave_ppl = (int)value; return GSF_OK;
+    if (strcmp(key, "lane_min_traj") == 0) {
+        if (value < 0) { set_error("gsf_set_option: lane_min_traj must be >= 0"); return GSF_ERR_INVALID_ARG; }
+        ctx->lane_min_traj = value; return GSF_OK;
     }
     set_error("gsf_set_option: unknown key '%s'", key);
     return GSF_ERR_INVALID_ARG;
@@ -152,43 +231,32 @@ int gsf_timer_stop(gsf_ctx* ctx, float* elapsed_ms)
 }
 
 // ------------------------------------------------------------------------------------------
-// host-pointer forms
+// host-pointer forms: pack -> one H2D -> *_dev launch -> one D2H -> synchronise (gsf::Staging)
 // ------------------------------------------------------------------------------------------
-#define H2D(dst, src, bytes) GSF_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
-#define D2H(dst, src, bytes) GSF_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->stream))
+#define ST_BEGIN(bytes, n) Staging st(ctx, (bytes), (n)); if (st.rc()) return st.rc()
+#define ST_RUN(call) do { int rc__ = st.upload(); if (rc__) return rc__; rc__ = (call); if (rc__) return rc__; return st.finish(); } while (0)
+
+static int utm_host(gsf_ctx* ctx, bool inverse, const double* a, const double* b, int64_t n, int32_t zone, int32_t south, double* oa, double* ob)
+{
+    GSF_REQUIRE(ctx && (n == 0 || (a && b && oa && ob)) && n >= 0, "bad arguments");
+    if (n == 0) return GSF_OK;
+    ST_BEGIN((size_t)n * 32 + 24, 6);
+    const int64_t off[2] = { 0, n }; const int32_t zs[2] = { zone, south };
+    const double* da = st.in(a, (size_t)n); const double* db = st.in(b, (size_t)n);
+    const int64_t* doff = st.in(off, 2); const int32_t* dzs = st.in(zs, 2);
+    double* doa = st.out(oa, (size_t)n); double* dob = st.out(ob, (size_t)n);
+    if (inverse) ST_RUN(gsf_utm_inverse_batch_dev(ctx, da, db, doff, dzs, dzs + 1, 1, doa, dob));
+    ST_RUN(gsf_utm_forward_batch_dev(ctx, da, db, doff, dzs, dzs + 1, 1, doa, dob));
+}
 
 int gsf_utm_forward(gsf_ctx* ctx, const double* lat, const double* lon, int64_t n, int32_t zone, int32_t south, double* e, double* nn)
 {
-    GSF_REQUIRE(ctx && (n == 0 || (lat && lon && e && nn)) && n >= 0, "bad arguments");
-    if (n == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    DevBuf b; GSF_HIP(b.alloc((size_t)n * 4 * sizeof(double) + 2 * sizeof(int64_t) + 2 * sizeof(int32_t)));
-    double* d = b.as<double>();
-    int64_t off[2] = { 0, n }; int32_t zs[2] = { zone, south };
-    int64_t* doff = (int64_t*)(d + 4 * n); int32_t* dzs = (int32_t*)(doff + 2);
-    H2D(d, lat, (size_t)n * 8); H2D(d + n, lon, (size_t)n * 8); H2D(doff, off, sizeof off); H2D(dzs, zs, sizeof zs);
-    int rc = gsf_utm_forward_batch_dev(ctx, d, d + n, doff, dzs, dzs + 1, 1, d + 2 * n, d + 3 * n);
-    if (rc) return rc;
-    D2H(e, d + 2 * n, (size_t)n * 8); D2H(nn, d + 3 * n, (size_t)n * 8);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return utm_host(ctx, false, lat, lon, n, zone, south, e, nn);
 }
 
 int gsf_utm_inverse(gsf_ctx* ctx, const double* e, const double* nn, int64_t n, int32_t zone, int32_t south, double* lat, double* lon)
 {
-    GSF_REQUIRE(ctx && (n == 0 || (lat && lon && e && nn)) && n >= 0, "bad arguments");
-    if (n == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    DevBuf b; GSF_HIP(b.alloc((size_t)n * 4 * sizeof(double) + 2 * sizeof(int64_t) + 2 * sizeof(int32_t)));
-    double* d = b.as<double>();
-    int64_t off[2] = { 0, n }; int32_t zs[2] = { zone, south };
-    int64_t* doff = (int64_t*)(d + 4 * n); int32_t* dzs = (int32_t*)(doff + 2);
-    H2D(d, e, (size_t)n * 8); H2D(d + n, nn, (size_t)n * 8); H2D(doff, off, sizeof off); H2D(dzs, zs, sizeof zs);
-    int rc = gsf_utm_inverse_batch_dev(ctx, d, d + n, doff, dzs, dzs + 1, 1, d + 2 * n, d + 3 * n);
-    if (rc) return rc;
-    D2H(lat, d + 2 * n, (size_t)n * 8); D2H(lon, d + 3 * n, (size_t)n * 8);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    return utm_host(ctx, true, e, nn, n, zone, south, lat, lon);
 }
 
 int gsf_sim3_umeyama_batch(gsf_ctx* ctx, const double* src, const double* dst, const uint8_t* mask, const int64_t* offsets,
@@ -196,22 +264,15 @@ int gsf_sim3_umeyama_batch(gsf_ctx* ctx, const double* src, const double* dst, c
 {
     GSF_REQUIRE(ctx && offsets && B >= 0 && R && t && s && status, "bad arguments");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    int64_t total = offsets[B];
+    const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (src && dst)), "bad offsets / NULL points");
-    DevBuf pts, msk, off, outb;
-    GSF_HIP(pts.alloc((size_t)total * 6 * 8)); GSF_HIP(off.alloc((size_t)(B + 1) * 8));
-    GSF_HIP(outb.alloc((size_t)B * (13 * 8 + 4)));
-    double* dsrc = pts.as<double>(); double* ddst = dsrc + total * 3;
-    H2D(dsrc, src, (size_t)total * 24); H2D(ddst, dst, (size_t)total * 24); H2D(off.p, offsets, (size_t)(B + 1) * 8);
-    uint8_t* dmask = nullptr;
-    if (mask) { GSF_HIP(msk.alloc((size_t)total)); dmask = msk.as<uint8_t>(); H2D(dmask, mask, (size_t)total); }
-    double* dR = outb.as<double>(); double* dt = dR + 9 * B; double* ds = dt + 3 * B; int32_t* dst_ = (int32_t*)(ds + B);
-    int rc = gsf_sim3_umeyama_batch_dev(ctx, dsrc, ddst, dmask, off.as<int64_t>(), B, dR, dt, ds, dst_);
-    if (rc) return rc;
-    D2H(R, dR, (size_t)B * 72); D2H(t, dt, (size_t)B * 24); D2H(s, ds, (size_t)B * 8); D2H(status, dst_, (size_t)B * 4);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    ST_BEGIN((size_t)total * 49 + (size_t)(B + 1) * 8 + (size_t)B * 108, 8);
+    const double* dsrc = st.in(src, (size_t)total * 3); const double* ddst = st.in(dst, (size_t)total * 3);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    const uint8_t* dmask = mask ? st.in(mask, (size_t)total) : nullptr;
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_sim3_umeyama_batch_dev(ctx, dsrc, ddst, dmask, doff, B, dR, dt, ds, dst_));
 }
 
 int gsf_sim3_ransac_batch(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, int64_t B,
@@ -221,25 +282,17 @@ int gsf_sim3_ransac_batch(gsf_ctx* ctx, const double* src, const double* dst, co
     GSF_REQUIRE(ctx && offsets && B >= 0 && R && t && s && status && inlier_mask && n_inliers, "bad arguments");
     GSF_REQUIRE(trials >= 0 && min_samples >= 1 && (trials == 0 || sample_idx), "bad trials/min_samples/sample_idx");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    int64_t total = offsets[B];
+    const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (src && dst)), "bad offsets / NULL points");
-    DevBuf pts, off, outb, idx, msk;
-    size_t nidx = (size_t)B * (size_t)trials * (size_t)min_samples;
-    GSF_HIP(pts.alloc((size_t)total * 6 * 8)); GSF_HIP(off.alloc((size_t)(B + 1) * 8)); GSF_HIP(idx.alloc(nidx * 4));
-    GSF_HIP(outb.alloc((size_t)B * (13 * 8 + 8))); GSF_HIP(msk.alloc((size_t)total));
-    double* dsrc = pts.as<double>(); double* ddst = dsrc + total * 3;
-    H2D(dsrc, src, (size_t)total * 24); H2D(ddst, dst, (size_t)total * 24); H2D(off.p, offsets, (size_t)(B + 1) * 8);
-    if (nidx) H2D(idx.p, sample_idx, nidx * 4);
-    double* dR = outb.as<double>(); double* dt = dR + 9 * B; double* ds = dt + 3 * B; int32_t* dst_ = (int32_t*)(ds + B); int32_t* dni = dst_ + B;
-    int rc = gsf_sim3_ransac_batch_dev(ctx, dsrc, ddst, off.as<int64_t>(), B, idx.as<int32_t>(), trials, min_samples, thr, min_inliers,
-                                       dR, dt, ds, dst_, msk.as<uint8_t>(), dni);
-    if (rc) return rc;
-    D2H(R, dR, (size_t)B * 72); D2H(t, dt, (size_t)B * 24); D2H(s, ds, (size_t)B * 8); D2H(status, dst_, (size_t)B * 4);
-    D2H(n_inliers, dni, (size_t)B * 4);
-    if (total) D2H(inlier_mask, msk.p, (size_t)total);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    const size_t nidx = (size_t)B * (size_t)trials * (size_t)min_samples;
+    ST_BEGIN((size_t)total * 49 + (size_t)(B + 1) * 8 + nidx * 4 + (size_t)B * 112, 10);
+    const double* dsrc = st.in(src, (size_t)total * 3); const double* ddst = st.in(dst, (size_t)total * 3);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    const int32_t* didx = st.in(sample_idx, nidx);
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    int32_t* dst_ = st.out(status, (size_t)B); int32_t* dni = st.out(n_inliers, (size_t)B);
+    uint8_t* dmask = st.out(inlier_mask, (size_t)total);
+    ST_RUN(gsf_sim3_ransac_batch_dev(ctx, dsrc, ddst, doff, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni));
 }
 
 int gsf_apply_sim3_batch(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R,
@@ -247,21 +300,15 @@ int gsf_apply_sim3_batch(gsf_ctx* ctx, const double* pos, const double* quat, co
 {
     GSF_REQUIRE(ctx && offsets && B >= 0 && R && t && s, "bad arguments");
     if (B == 0) return GSF_OK;
-    GSF_HIP(hipSetDevice(ctx->device));
-    int64_t total = offsets[B];
+    const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (pos && quat && pos_out && quat_out)), "bad offsets / NULL poses");
-    DevBuf io, off, par;
-    GSF_HIP(io.alloc((size_t)total * 14 * 8)); GSF_HIP(off.alloc((size_t)(B + 1) * 8)); GSF_HIP(par.alloc((size_t)B * (13 * 8 + 4)));
-    double* dpos = io.as<double>(); double* dquat = dpos + 3 * total; double* dpo = dquat + 4 * total; double* dqo = dpo + 3 * total;
-    double* dR = par.as<double>(); double* dt = dR + 9 * B; double* ds = dt + 3 * B; int32_t* dbad = (int32_t*)(ds + B);
-    H2D(dpos, pos, (size_t)total * 24); H2D(dquat, quat, (size_t)total * 32); H2D(off.p, offsets, (size_t)(B + 1) * 8);
-    H2D(dR, R, (size_t)B * 72); H2D(dt, t, (size_t)B * 24); H2D(ds, s, (size_t)B * 8);
-    int rc = gsf_apply_sim3_batch_dev(ctx, dpos, dquat, off.as<int64_t>(), B, dR, dt, ds, dpo, dqo, dbad);
-    if (rc) return rc;
-    if (total) { D2H(pos_out, dpo, (size_t)total * 24); D2H(quat_out, dqo, (size_t)total * 32); }
-    if (bad_quat) D2H(bad_quat, dbad, (size_t)B * 4);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    ST_BEGIN((size_t)total * 112 + (size_t)(B + 1) * 8 + (size_t)B * 108, 9);
+    const double* dpos = st.in(pos, (size_t)total * 3); const double* dquat = st.in(quat, (size_t)total * 4);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    const double* dR = st.in(R, (size_t)B * 9); const double* dt = st.in(t, (size_t)B * 3); const double* ds = st.in(s, (size_t)B);
+    double* dpo = st.out(pos_out, (size_t)total * 3); double* dqo = st.out(quat_out, (size_t)total * 4);
+    int32_t* dbad = st.out(bad_quat, (size_t)B);
+    ST_RUN(gsf_apply_sim3_batch_dev(ctx, dpos, dquat, doff, B, dR, dt, ds, dpo, dqo, dbad));
 }
 
 int gsf_ekf_fuse_batch(gsf_ctx* ctx, int32_t layout, const double* ts, const double* pos, const double* quat, const double* gps,
@@ -271,22 +318,13 @@ int gsf_ekf_fuse_batch(gsf_ctx* ctx, int32_t layout, const double* ts, const dou
     GSF_REQUIRE(ctx && cfg && B >= 0 && N >= 0, "bad arguments");
     if (B == 0 || N == 0) return GSF_OK;
     GSF_REQUIRE(ts && pos && quat && gps && valid && init_pos && init_quat && pos_out && quat_out, "NULL array");
-    GSF_HIP(hipSetDevice(ctx->device));
-    size_t P = (size_t)B * (size_t)N;
-    DevBuf in, outb;
-    GSF_HIP(in.alloc(P * (11 * 8 + 1) + (size_t)B * 7 * 8 + 64));
-    GSF_HIP(outb.alloc(P * 7 * 8 + (size_t)B * 4));
-    double* dts = in.as<double>(); double* dpos = dts + P; double* dquat = dpos + 3 * P; double* dgps = dquat + 4 * P;
-    double* dip = dgps + 3 * P; double* diq = dip + 3 * B; uint8_t* dval = (uint8_t*)(diq + 4 * B);
-    double* dpo = outb.as<double>(); double* dqo = dpo + 3 * P; int32_t* dst_ = (int32_t*)(dqo + 4 * P);
-    H2D(dts, ts, P * 8); H2D(dpos, pos, P * 24); H2D(dquat, quat, P * 32); H2D(dgps, gps, P * 24); H2D(dval, valid, P);
-    H2D(dip, init_pos, (size_t)B * 24); H2D(diq, init_quat, (size_t)B * 32);
-    int rc = gsf_ekf_fuse_batch_dev(ctx, layout, dts, dpos, dquat, dgps, dval, dip, diq, cfg, B, N, dpo, dqo, dst_);
-    if (rc) return rc;
-    D2H(pos_out, dpo, P * 24); D2H(quat_out, dqo, P * 32);
-    if (status) D2H(status, dst_, (size_t)B * 4);
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    const size_t P = (size_t)B * (size_t)N;
+    ST_BEGIN(P * 145 + (size_t)B * 60, 10);
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgps = st.in(gps, P * 3); const uint8_t* dval = st.in(valid, P);
+    const double* dip = st.in(init_pos, (size_t)B * 3); const double* diq = st.in(init_quat, (size_t)B * 4);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_ekf_fuse_batch_dev(ctx, layout, dts, dpos, dquat, dgps, dval, dip, diq, cfg, B, N, dpo, dqo, dst_));
 }
 
 }  // extern "C"

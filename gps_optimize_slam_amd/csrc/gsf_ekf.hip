@@ -200,6 +200,34 @@ EkfConfig to_core(const gsf_ekf_config* c)
 
 }  // namespace
 
+// A time-major batch with fewer trajectories than ctx->lane_min_traj cannot fill the chip with one lane per trajectory (64 tracks per
+// wave: 1 000 tracks are 16 waves on 1 024 SIMDs, 0.9 ms instead of 25 us at C2).  Such batches are transposed into the context's
+// workspace, fused by the wave-per-trajectory kernel and transposed back: 3 x 145 B/pose of traffic instead of 145, which still wins
+// below ~32 k trajectories (measured crossover).  Workspace: 145 B/pose, capped at 8 GB.
+static bool route_time_major_through_wave(const gsf_ctx* ctx, int64_t B, int64_t N)
+{
+    return B < ctx->lane_min_traj && (double)B * (double)N * 145.0 <= 8.0e9;
+}
+
+static int fuse_time_major_via_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
+                                    const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                                    int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
+{
+    const size_t P = (size_t)B * (size_t)N;
+    int rc = ensure_scratch(ctx, P * (18 * 8) + ((P + 7) & ~(size_t)7) + 64);
+    if (rc) return rc;
+    double* wts = (double*)ctx->scratch; double* wpos = wts + P; double* wquat = wpos + 3 * P; double* wgps = wquat + 4 * P;
+    double* wpo = wgps + 3 * P; double* wqo = wpo + 3 * P; uint8_t* wval = (uint8_t*)(wqo + 4 * P);
+    if ((rc = gsf_transpose_to_traj_major_dev(ctx, ts, wts, B, N, 1, 8))) return rc;
+    if ((rc = gsf_transpose_to_traj_major_dev(ctx, pos, wpos, B, N, 3, 8))) return rc;
+    if ((rc = gsf_transpose_to_traj_major_dev(ctx, quat, wquat, B, N, 4, 8))) return rc;
+    if ((rc = gsf_transpose_to_traj_major_dev(ctx, gps, wgps, B, N, 3, 8))) return rc;
+    if ((rc = gsf_transpose_to_traj_major_dev(ctx, valid, wval, B, N, 1, 1))) return rc;
+    if ((rc = launch_ekf_wave(ctx, pipeline, wts, wpos, wquat, wgps, wval, init_pos, init_quat, cfg, B, N, R, t, s, wpo, wqo, status))) return rc;
+    if ((rc = gsf_transpose_to_time_major_dev(ctx, wpo, pos_out, B, N, 3, 8))) return rc;
+    return gsf_transpose_to_time_major_dev(ctx, wqo, quat_out, B, N, 4, 8);
+}
+
 extern "C" int gsf_ekf_fuse_batch_dev(gsf_ctx* ctx, int32_t layout, const double* ts, const double* pos, const double* quat,
                                       const double* gps, const uint8_t* valid, const double* init_pos, const double* init_quat,
                                       const gsf_ekf_config* cfg, int64_t B, int64_t N, double* pos_out, double* quat_out,
@@ -213,29 +241,14 @@ extern "C" int gsf_ekf_fuse_batch_dev(gsf_ctx* ctx, int32_t layout, const double
     GSF_REQUIRE(B <= (int64_t)0x7fffffff * 64, "B too large for one launch");
     for (int i = 0; i < 7; ++i) GSF_REQUIRE(cfg->initial_cov_diag[i] == cfg->initial_cov_diag[i], "NaN in config");
     GSF_HIP(hipSetDevice(ctx->device));
+    if (layout == GSF_LAYOUT_TRAJ_MAJOR)                               // wave-per-trajectory scans (gsf_ekf_wave.hip)
+        return launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr, pos_out, quat_out, status);
+    if (route_time_major_through_wave(ctx, B, N))
+        return fuse_time_major_via_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr, pos_out, quat_out, status);
     const EkfConfig k = to_core(cfg);
     const dim3 block(64), grid((unsigned)((B + 63) / 64));
-#define GSF_LAUNCH_EKF(LAY, PF, OCC)                                                                                        \
-    hipLaunchKernelGGL((ekf_fuse_kernel<LAY, PF, OCC>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, init_pos,   \
-                       init_quat, k, B, N, pos_out, quat_out, status)
-    if (layout == GSF_LAYOUT_TIME_MAJOR) {
-        switch (ctx->ekf_variant) {          // prefetch depth / occupancy trade-off, see DESIGN.md "K4 tuning"
-            case 1: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 4, 1); break;
-            case 2: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 1, 2); break;
-            case 3: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 1, 3); break;
-            case 4: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 3, 1); break;
-            default: GSF_LAUNCH_EKF(GSF_LAYOUT_TIME_MAJOR, 2, 2); break;
-        }
-    } else if (ctx->ekf_variant == 9) {
-        GSF_LAUNCH_EKF(GSF_LAYOUT_TRAJ_MAJOR, 2, 2);                   // lane-per-trajectory on strided rows (comparison only)
-    } else if (use_block_kernel(ctx, B, N)) {
-        return launch_ekf_block(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr,
-                                pos_out, quat_out, status);            // wave-per-chunk scans (gsf_ekf_block.hip)
-    } else {
-        return launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, nullptr, nullptr, nullptr,
-                               pos_out, quat_out, status);             // wave-per-trajectory scans (gsf_ekf_wave.hip)
-    }
-#undef GSF_LAUNCH_EKF
+    hipLaunchKernelGGL((ekf_fuse_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, init_pos, init_quat, k, B, N,
+                       pos_out, quat_out, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -251,18 +264,14 @@ extern "C" int gsf_fuse_pipeline_batch_dev(gsf_ctx* ctx, int32_t layout, const d
     GSF_REQUIRE(ts && pos && quat && gps && valid && R && t && s && pos_out && quat_out, "NULL array");
     GSF_REQUIRE(B <= (int64_t)0x7fffffff * 64, "B too large for one launch");
     GSF_HIP(hipSetDevice(ctx->device));
+    if (layout == GSF_LAYOUT_TRAJ_MAJOR)
+        return launch_ekf_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
+    if (route_time_major_through_wave(ctx, B, N))
+        return fuse_time_major_via_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
     const EkfConfig k = to_core(cfg);
     const dim3 block(64), grid((unsigned)((B + 63) / 64));
-    if (layout == GSF_LAYOUT_TIME_MAJOR)
-        hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
-                           R, t, s, pos_out, quat_out, status);
-    else if (ctx->ekf_variant == 9)
-        hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TRAJ_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
-                           R, t, s, pos_out, quat_out, status);
-    else if (use_block_kernel(ctx, B, N))
-        return launch_ekf_block(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
-    else
-        return launch_ekf_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
+    hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
+                       R, t, s, pos_out, quat_out, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -81,12 +81,6 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
     }
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
 }  // namespace
 
 extern "C" {
@@ -109,20 +103,17 @@ int gsf_eval_errors_batch(gsf_ctx* ctx, const double* ts, const double* traj_pos
     GSF_REQUIRE(ctx && B >= 0 && N >= 0, "bad arguments");
     if (B == 0 || N == 0) return GSF_OK;
     GSF_REQUIRE(ts && traj_pos && aligned_gps && valid && stats, "NULL array");
-    GSF_HIP(hipSetDevice(ctx->device));
     const size_t P = (size_t)B * (size_t)N;
-    DevBuf d; GSF_HIP(d.alloc(P * (8 + 24 + 24 + 8 + 1) + (size_t)B * 32 + 64));
-    double* dts = (double*)d.p; double* dp = dts + P; double* dg = dp + 3 * P; double* de = dg + 3 * P; double* dst = de + P; uint8_t* dv = (uint8_t*)(dst + 4 * B);
-    GSF_HIP(hipMemcpyAsync(dts, ts, P * 8, hipMemcpyHostToDevice, ctx->stream));
-    GSF_HIP(hipMemcpyAsync(dp, traj_pos, P * 24, hipMemcpyHostToDevice, ctx->stream));
-    GSF_HIP(hipMemcpyAsync(dg, aligned_gps, P * 24, hipMemcpyHostToDevice, ctx->stream));
-    GSF_HIP(hipMemcpyAsync(dv, valid, P, hipMemcpyHostToDevice, ctx->stream));
-    int rc = gsf_eval_errors_batch_dev(ctx, dts, dp, dg, dv, B, N, skip_seconds, dst, de);
+    Staging st(ctx, P * 65 + (size_t)B * 32, 6);
+    if (st.rc()) return st.rc();
+    const double* dts = st.in(ts, P); const double* dp = st.in(traj_pos, P * 3); const double* dg = st.in(aligned_gps, P * 3);
+    const uint8_t* dv = st.in(valid, P);
+    double* dst = st.out(stats, (size_t)B * 4); double* de = st.out(errors, P);
+    int rc = st.upload();
     if (rc) return rc;
-    GSF_HIP(hipMemcpyAsync(stats, dst, (size_t)B * 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (errors) GSF_HIP(hipMemcpyAsync(errors, de, P * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GSF_HIP(hipStreamSynchronize(ctx->stream));
-    return GSF_OK;
+    rc = gsf_eval_errors_batch_dev(ctx, dts, dp, dg, dv, B, N, skip_seconds, dst, de);
+    if (rc) return rc;
+    return st.finish();
 }
 
 }  // extern "C"

@@ -12,13 +12,17 @@ struct gsf_ctx {
     hipStream_t stream;
     bool owns_stream;
     hipEvent_t ev0, ev1;
-    // scratch for the fused pipeline (R,t,s,status per trajectory + init poses), grown on demand
+    // kernel workspace (time-alignment slabs, the transposed copy of a small time-major batch), grown on demand
     void* scratch;
     size_t scratch_bytes;
-    int ekf_variant;       // tuning knob (gsf_set_option "ekf_variant")
-    int wave_ppl;          // poses per lane of the wave-per-trajectory kernels (gsf_set_option "wave_ppl"; 0 = automatic)
+    // staging of the host-pointer entry points: one grow-only device arena + a pinned host mirror (see gsf::Staging)
+    void* stage;
+    size_t stage_bytes;
+    void* pinned;
+    size_t pinned_bytes;
+    int ekf_variant;       // reserved tuning knob (gsf_set_option "ekf_variant"); 0 = default
     int duo_kernel;        // two-wave pipeline kernel for small batches (gsf_set_option "duo_kernel"): -1 automatic, 0 never, 1 always
-    int seg_kernel;        // single-shot kernel for short tracks (gsf_set_option "seg_kernel"): 1 = whenever N fits, otherwise never (opt-in)
+    int64_t lane_min_traj; // time-major batches with fewer trajectories are transposed and run by the wave kernel (gsf_set_option "lane_min_traj")
 };
 
 namespace gsf {
@@ -56,24 +60,30 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
                     const int64_t* offsets = nullptr);
 
-// single-shot kernel for short tracks: the whole trajectory in one wave pass, ceil(N/64) consecutive poses per lane
-// (gsf_ekf_seg.hip), equal-length batches with N <= 64 * SEG_MAX_P
-constexpr int SEG_MAX_P = 5;
-int launch_ekf_seg(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
-                   const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
-                   int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
+// Staging of the host-pointer entry points.  ONE grow-only device arena per context plus a pinned host mirror of it: the
+// inputs of a call are packed into the mirror and cross PCIe in one hipMemcpyAsync, the outputs come back in one, and no call
+// pays hipMalloc/hipFree (which synchronise the device).  Calls whose arrays exceed PINNED_MAX copy straight from/to the caller's
+// pageable arrays instead (a bulk transfer, where the extra host memcpy would cost more than the runtime's own staging).
+// Order of use: every in() before the first out()/tmp(); upload(); launches; finish().
+class Staging {
+public:
+    static constexpr size_t PINNED_MAX = (size_t)32 << 20;
+    Staging(gsf_ctx* ctx, size_t payload_bytes, int n_arrays);
+    int rc() const { return rc_; }
+    template <class T> T* in(const T* host, size_t n) { return (T*)in_bytes(host, n * sizeof(T)); }
+    template <class T> T* out(T* host, size_t n) { return (T*)out_bytes(host, n * sizeof(T)); }
+    template <class T> T* tmp(size_t n) { return (T*)out_bytes(nullptr, n * sizeof(T)); }
+    int upload();
+    int finish();      // device -> caller arrays, then hipStreamSynchronize
 
-// wave-per-chunk / block-per-trajectory variant for small batches of short tracks (gsf_ekf_block.hip), N <= 1024
-int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
-                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
-                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
-// trajectory-major dispatch.  Measured on MI355X: the chunk-parallel block kernel is SLOWER than the serial
-// wave kernel even at C2 (1 000 x 271: 29 us vs 22 us for K4) -- 1 000 waves already occupy all 1 024 SIMDs and the serial kernel
-// is ~60 % issue-bound, so extra waves only add carry-composition / barrier work.  It is therefore opt-in (ekf_variant 8 / 6).
-inline bool use_block_kernel(const gsf_ctx* ctx, int64_t B, int64_t N)
-{
-    (void)B;
-    return N <= 1024 && (ctx->ekf_variant == 8 || ctx->ekf_variant == 6);
-}
+private:
+    struct Out { void* host; size_t off, bytes; };
+    static constexpr int MAX_OUT = 16;
+    void* take(size_t bytes, size_t& at);
+    void* in_bytes(const void* host, size_t bytes);
+    void* out_bytes(void* host, size_t bytes);
+    gsf_ctx* ctx_; char* d_ = nullptr; char* h_ = nullptr; size_t cap_ = 0, off_ = 0, in_end_ = 0, out_lo_ = 0; bool direct_ = false, has_out_ = false;
+    int rc_ = GSF_OK; Out outs_[MAX_OUT]; int n_out_ = 0;
+};
 
 }  // namespace gsf

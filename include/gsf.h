@@ -91,7 +91,11 @@ GSF_API int gsf_create(int device_id, gsf_ctx **out);
 GSF_API int gsf_create_on_stream(int device_id, void *hip_stream, gsf_ctx **out);
 GSF_API void gsf_destroy(gsf_ctx *ctx);
 GSF_API int gsf_synchronize(gsf_ctx *ctx);
-/* tuning knobs; keys: "ekf_variant" (0 default; prefetch-depth/occupancy variants of K4) */
+/* tuning knobs; keys:
+     "duo_kernel"     -1 automatic (default) / 0 never / 1 always: two-wave build of the fused pipeline for small batches of short tracks
+     "lane_min_traj"  time-major batches with fewer trajectories than this (default 32768) are transposed and run by the
+                      wave-per-trajectory kernel; 0 = always the lane-per-trajectory kernel
+     "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
 /* opens / closes a HIP-event bracket on the context's stream; gsf_timer_stop returns the elapsed ms */
 GSF_API int gsf_timer_start(gsf_ctx *ctx);
@@ -238,9 +242,18 @@ GSF_API int gsf_rts_smoother_segment_batch(gsf_ctx *ctx, const double *states_fi
                                            double *covs_smooth);
 
 /* ---- multi-GPU collect: RCCL all-gather of the fused poses over xGMI ------------------------------- */
-/* All-gather `count` doubles per rank into recv[world][count], asynchronously on the context's stream, on a caller-provided
-   ncclComm_t (RCCL is resolved at run time).  mode 0 = one ncclAllGather; mode 1 = direct exchange (grouped
-   ncclSend/ncclRecv with every peer, `chunk_count` doubles at a time) so all point-to-point links carry traffic at once. */
+/* The reference is single-process (no collective exists in it: filter state is per ExtendedKalmanFilter instance,
+   EKFGPSSLAM.py:842); trajectories shard by contiguous id blocks, one process per GPU, and this is the one exchange: every rank
+   receives every rank's fused poses.  RCCL is resolved at run time (dlopen).
+   gsf_comm_unique_id: 128-byte ncclUniqueId (rank 0 creates it, the host ships it to the other ranks by any side channel);
+   gsf_comm_init_rank: collective over all `world` processes, device = the context's; gsf_comm_destroy frees the communicator. */
+GSF_API int gsf_comm_unique_id(uint8_t *id128);
+GSF_API int gsf_comm_init_rank(gsf_ctx *ctx, const uint8_t *id128, int32_t world, int32_t rank, void **comm);
+GSF_API int gsf_comm_destroy(void *comm);
+/* All-gather `count` doubles per rank into recv[world][count], asynchronously on the context's stream, on a communicator from
+   gsf_comm_init_rank (or any caller-provided ncclComm_t).  mode 0 = one ncclAllGather; mode 1 = direct exchange (grouped
+   ncclSend/ncclRecv with every peer, `chunk_count` doubles at a time; 0 = all at once) so all seven point-to-point xGMI links of
+   a GPU carry traffic at once. */
 GSF_API int gsf_allgather_poses(gsf_ctx *ctx, void *nccl_comm, const double *send, double *recv, int64_t count, int32_t mode,
                                 int64_t chunk_count);
 

@@ -291,6 +291,23 @@ def fuse_pipeline_batch(ts, pos, quat, aligned, valid, cfg=None):
     return po, qo, st, R, t, s
 
 
+def evaluate_trajectory_errors(ts, traj_pos, aligned, valid, skip_seconds=5.0):
+    """The reference's error metric (main_process_gui step 6, EKFGPSSLAM.py:1013-1033): for every index with valid
+    aligned GNSS and ts > ts[0] + skip, the MINIMUM Euclidean distance to ANY such candidate fix (cdist + min, :1030-1031), then
+    mean / median / RMSE (:1033).  Plain NumPy (no SciPy).  Returns dict(count, mean, median, rmse, errors)."""
+    ts, traj_pos, aligned = _a(ts).ravel(), _a(traj_pos).reshape(-1, 3), _a(aligned).reshape(-1, 3)
+    ok = np.asarray(valid).astype(bool).ravel() & ~np.isnan(aligned).any(axis=1)
+    post = np.where(ok & (ts > ts[0] + skip_seconds))[0]                                   # :1015-1023
+    errors = np.full(ts.size, np.nan)
+    if post.size == 0:
+        return {"count": 0, "mean": np.nan, "median": np.nan, "rmse": np.nan, "errors": errors}
+    cand = aligned[post]                                                                   # :1024
+    d = np.sqrt(((traj_pos[post][:, None, :] - cand[None, :, :]) ** 2).sum(axis=2)).min(axis=1)   # :1030-1031
+    errors[post] = d
+    return {"count": int(post.size), "mean": float(d.mean()), "median": float(np.median(d)),
+            "rmse": float(np.sqrt((d ** 2).mean())), "errors": errors}
+
+
 def dynamic_time_alignment(slam_t, gps_t, gps_p, max_samples=500, max_gap=5.0):
     st, gt, gp = _a(slam_t).ravel(), _a(gps_t).ravel(), _a(gps_p).reshape(-1, 3)
     al = np.empty((st.size, 3))

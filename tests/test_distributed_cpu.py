@@ -44,6 +44,19 @@ def _worker(rank, world, port, total, n, out_dir):
     sums = []
     D.allgather_poses(pos, quat, chunk_trajs=3, sink=lambda k, p, q: sums.append(float(p.sum() + q.sum())))
     assert abs(sum(sums) - float(full_p.sum() + full_q.sum())) < 1e-6 * abs(float(full_p.sum()))
+    # time-major tensors (N, C, B): the trajectory axis is the LAST one (traj_dim=-1)
+    pt, qt = pos.permute(1, 2, 0).contiguous(), quat.permute(1, 2, 0).contiguous()
+    pa, qa = D.allgather_poses(pt, qt, traj_dim=-1)
+    assert torch.equal(torch.cat(list(pa), dim=2), full_p.permute(1, 2, 0)) and torch.equal(torch.cat(list(qa), dim=2), full_q.permute(1, 2, 0))
+    got = []
+    D.allgather_poses(pt, qt, chunk_trajs=2, traj_dim=-1, sink=lambda k, p, q: got.append((p.shape, q.shape)))
+    assert got[0] == ((world, n, 3, 2), (world, n, 4, 2)) and len(got) == -(-(hi - lo) // 2)
+    with pytest.raises(ValueError):
+        D.allgather_poses(pt, qt, traj_dim=5)
+    flat = torch.empty((world * pos.numel(),), dtype=torch.float64)
+    D.all_gather_flat(flat, pos.reshape(-1))
+    assert torch.equal(flat.view(total, n, 3), full_p)
+    assert int(D.all_reduce(torch.tensor([rank + 1])).item()) == world * (world + 1) // 2
     t = D.max_over_ranks(1.0 + rank, "cpu")
     assert t == float(world)
     D.barrier()

@@ -7,8 +7,12 @@ quaternion components within 1e-9."""
 import copy
 import json
 
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -194,13 +198,33 @@ def B():
     return batch
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+import contextlib
+
+
+@contextlib.contextmanager
+def route(B, layout):
+    """layout "lane": a time-major batch on the lane-per-trajectory kernel even when it is small (by default time-major batches
+    below 32 768 trajectories are transposed and run by the wave-per-trajectory kernel -- layout 1 then exercises that route)."""
+    if layout == "lane":
+        B.context().set_option("lane_min_traj", 0)
+    try:
+        yield 1 if layout == "lane" else layout
+    finally:
+        if layout == "lane":
+            B.context().set_option("lane_min_traj", 32768)
+
+
+LAYOUTS = [0, 1, "lane"]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("N", [271, 64, 65, 1000, 3])
 def test_synth_batch_vs_oracle(B, orc, layout, N):
     """Config C2-shaped batch (KITTI-04 length) -- every trajectory against the dense-7x7 CPU oracle."""
     nb = 700 if N < 1000 else 300
-    batch = B.TrajectoryBatch.synthetic(nb, N, layout=layout, seed=7)
-    out = B.ekf_fuse_batch(batch)
+    with route(B, layout) as lay:
+        batch = B.TrajectoryBatch.synthetic(nb, N, layout=lay, seed=7)
+        out = B.ekf_fuse_batch(batch)
     h = batch.host_traj_major()
     p, q, st = out.host_traj_major()
     po, qo, sto = orc.fuse_batch(h["ts"], h["pos"], h["quat"], h["gps"], h["valid"], h["init_pos"], h["init_quat"])
@@ -215,45 +239,41 @@ def test_synth_batch_vs_oracle(B, orc, layout, N):
 
 
 def test_layouts_agree_and_shard_invariant(B):
-    """time-major = lane-per-trajectory recursion, trajectory-major = wave-per-trajectory scans: two different
-    evaluation orders of the same filter must agree far inside the gate; the status bits exactly."""
+    """time-major on the lane kernel = lane-per-trajectory recursion, trajectory-major = wave-per-trajectory scans: two different
+    evaluation orders of the same filter must agree far inside the gate; the status bits exactly.  A SMALL time-major batch takes
+    the transpose -> wave kernel -> transpose route by default and must then equal the trajectory-major result bit for bit."""
     nb, N = 3000, 200
     tm = B.TrajectoryBatch.synthetic(nb, N, layout=1, seed=11)
     pj = tm.to_layout(0)
-    p1, q1, s1 = B.ekf_fuse_batch(tm).host_traj_major()
+    with route(B, "lane"):
+        p1, q1, s1 = B.ekf_fuse_batch(tm).host_traj_major()
     p0, q0, s0 = B.ekf_fuse_batch(pj).host_traj_major()
     assert np.abs(p1 - p0).max() < POS_TOL and np.abs(q1 - q0).max() < Q_TOL
     np.testing.assert_array_equal(s1, s0)
-    B.context().set_option("ekf_variant", 9)            # the lane kernel on trajectory-major rows: same code as time-major
-    try:
-        p9, q9, s9 = B.ekf_fuse_batch(pj).host_traj_major()
-    finally:
-        B.context().set_option("ekf_variant", 0)
-    np.testing.assert_array_equal(p9, p1); np.testing.assert_array_equal(q9, q1); np.testing.assert_array_equal(s9, s1)
-    # trajectory-major: bit for bit with the default build and with a pinned multi-pose build
+    pw, qw, sw = B.ekf_fuse_batch(tm).host_traj_major()                 # default route of a small time-major batch
+    np.testing.assert_array_equal(pw, p0); np.testing.assert_array_equal(qw, q0); np.testing.assert_array_equal(sw, s0)
+    ow, Rw, tw, sw_ = B.fuse_pipeline_batch(tm)
+    oj, Rj, tj, sj = B.fuse_pipeline_batch(pj)
+    for x, y in zip(ow.host_traj_major(), oj.host_traj_major()):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(Rw.cpu().numpy(), Rj.cpu().numpy())
+    # shards generated independently (traj0 offset) == slices of the full batch, bit for bit (SURVEY 8e)
     parts0 = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=0, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
     np.testing.assert_array_equal(np.concatenate([x[0] for x in parts0]), p0)
+    np.testing.assert_array_equal(np.concatenate([x[1] for x in parts0]), q0)
     np.testing.assert_array_equal(np.concatenate([x[2] for x in parts0]), s0)
-    for ppl in (1, 5):
-        B.context().set_option("wave_ppl", ppl)
-        try:
-            full = B.ekf_fuse_batch(pj).host_traj_major()
-            parts0 = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=0, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
-        finally:
-            B.context().set_option("wave_ppl", 0)
-        np.testing.assert_array_equal(np.concatenate([x[0] for x in parts0]), full[0])
-        np.testing.assert_array_equal(np.concatenate([x[1] for x in parts0]), full[1])
-    # shards generated independently (traj0 offset) == slices of the full batch, bit for bit (SURVEY 8e)
-    parts = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=1, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
+    with route(B, "lane"):
+        parts = [B.ekf_fuse_batch(B.TrajectoryBatch.synthetic(1000, N, layout=1, seed=11, traj0=k * 1000)).host_traj_major() for k in range(3)]
     np.testing.assert_array_equal(np.concatenate([x[0] for x in parts]), p1)
     np.testing.assert_array_equal(np.concatenate([x[2] for x in parts]), s1)
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", LAYOUTS)
 def test_pipeline_batch_vs_oracle(B, orc, layout):
     nb, N = 400, 271
-    batch = B.TrajectoryBatch.synthetic(nb, N, layout=layout, seed=3)
-    out, R, t, s = B.fuse_pipeline_batch(batch)
+    with route(B, layout) as lay:
+        batch = B.TrajectoryBatch.synthetic(nb, N, layout=lay, seed=3)
+        out, R, t, s = B.fuse_pipeline_batch(batch)
     h = batch.host_traj_major()
     p, q, st = out.host_traj_major()
     R, t, s = R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy()
@@ -268,26 +288,18 @@ def test_pipeline_batch_vs_oracle(B, orc, layout):
         assert (st[b] & 0xff) == sto
 
 
-@pytest.mark.parametrize("variant", [("ekf_variant", 8), ("ekf_variant", 5), ("wave_ppl", 1), ("wave_ppl", 2), ("wave_ppl", 3),
-                                     ("wave_ppl", 4), ("wave_ppl", 5), ("seg_kernel", 1)], ids=lambda v: f"{v[0]}{v[1]}")
 @pytest.mark.parametrize("N", [271, 1000, 64, 130, 321])
-def test_trajectory_major_kernel_variants_vs_oracle(B, orc, N, variant):
-    """Every trajectory-major build -- one to five poses per lane (wave_ppl 1..5; automatic = 1), the chunk-parallel block kernel
-    (ekf_variant 8), the historical two-pose switch (ekf_variant 5) and the single-shot short-track kernel (seg_kernel 1, N <= 320)
-    -- against the oracle, incl. the generic bad-quaternion path."""
+def test_trajectory_major_kernels_vs_oracle(B, orc, N):
+    """The wave-per-trajectory K4 and fused pipeline against the oracle, incl. the generic bad-quaternion path.  (The measured-and-
+    rejected builds of round 1 -- several poses per lane, block kernel, single-shot kernel -- live under tools/experiments/.)"""
     import torch
     nb = 300
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=21)
     batch.quat[5, N // 2] = 0.0                      # one invalid quaternion -> generic (non-telescoped) path for track 5
     batch.quat[9, 0] = 0.0
-    ctx = B.context()
-    ctx.set_option(*variant)
-    try:
-        out = B.ekf_fuse_batch(batch)
-        outp, R, t, s = B.fuse_pipeline_batch(batch)
-        torch.cuda.synchronize()
-    finally:
-        ctx.set_option(variant[0], 0)
+    out = B.ekf_fuse_batch(batch)
+    outp, R, t, s = B.fuse_pipeline_batch(batch)
+    torch.cuda.synchronize()
     h = batch.host_traj_major()
     p, q, st = out.host_traj_major()
     po, qo, sto = orc.fuse_batch(h["ts"], h["pos"], h["quat"], h["gps"], h["valid"], h["init_pos"], h["init_quat"])
@@ -424,18 +436,18 @@ def test_extended_kalman_filter_class(E, golden, tag):
         E.ExtendedKalmanFilter(np.zeros(2), np.zeros(4), E.CONFIG["ekf"])
 
 
-def test_rccl_allgather_wrapper_single_rank(B):
-    """gsf_allgather_poses on a 1-rank RCCL communicator (the box has one GPU): both modes must reproduce the send buffer."""
+def test_rccl_own_communicator_single_rank(B):
+    """gsf_comm_unique_id / gsf_comm_init_rank / gsf_allgather_poses / gsf_comm_destroy on a 1-rank communicator (the box has one
+    GPU): both exchange modes must reproduce the send buffer.  (World >= 2 over RCCL needs >= 2 GPUs: the driver's 8-GPU run.)"""
     import ctypes as C
-    import os
     import torch
     from gps_optimize_slam_amd import _lib
     L = _lib.load()
     ctx = B.context()
-    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    ident = (C.c_uint8 * 128)()
+    _lib.check(L.gsf_comm_unique_id(ident))
     comm = C.c_void_p()
-    devs = (C.c_int * 1)(torch.cuda.current_device())
-    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    _lib.check(L.gsf_comm_init_rank(ctx.handle, ident, 1, 0, C.byref(comm)))
     try:
         send = torch.randn(100_003, dtype=torch.float64, device="cuda")
         for mode, chunk in ((0, 0), (1, 0), (1, 4096)):
@@ -443,8 +455,60 @@ def test_rccl_allgather_wrapper_single_rank(B):
             _lib.check(L.gsf_allgather_poses(ctx.handle, comm, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), mode, chunk))
             torch.cuda.synchronize()
             assert torch.equal(send, recv), (mode, chunk)
+        assert L.gsf_comm_init_rank(ctx.handle, ident, 1, 3, C.byref(C.c_void_p())) != 0      # rank out of range: refused before RCCL is called
     finally:
-        rccl.ncclCommDestroy(comm)
+        _lib.check(L.gsf_comm_destroy(comm))
+
+
+def _run_ranks(script_args, world, timeout=600):
+    """start `world` ranks of a helper script (children of this process; they share the box's one GPU -> gloo rehearsal)"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable] + script_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return outs
+
+
+def test_two_rank_real_kernels_gathered_equals_unsharded(tmp_path):
+    """SURVEY 8e on hardware as far as a one-GPU box allows: two ranks fuse their shards with the REAL kernels, the collect goes
+    through the product's all-gather helpers (both layouts, whole + chunked with a checksum sink + the bench's one-call form), and
+    the gathered result equals the unsharded run bit for bit."""
+    out = tmp_path / "res.json"
+    _run_ranks([os.path.join(ROOT, "tests", "two_rank_worker.py"), str(out), "300", "271"], world=2)
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["backend"] == "gloo"
+    for layout in (0, 1):
+        for key in ("pos_equal", "quat_equal", "chunked_checksum_equal", "flat_blocks_equal", "finite"):
+            assert res[f"layout{layout}_{key}"] is True, (layout, key, res)
+
+
+def test_bench_two_ranks_self_spawned():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks (gloo rehearsal on the one GPU), exits 0 and prints ONE JSON
+    line with the collect block (gathered blocks == every rank's own checksum) and the C5-shaped leg."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    assert d["collect"]["gathered_blocks_equal_rank_checksums"] is True and d["collect"]["backend"] == "gloo"
+    assert d["max_abs_pos_err_m"] < 1e-6 and d["status_bits_equal"] is True
+    c5 = d["c5"]
+    assert "error" not in c5, c5
+    assert c5["chunks"] >= 2 and c5["collect"]["torch_all_gather"]["gathered_checksum_equals_sum_of_rank_checksums"] is True
+    assert abs(d["value"] - 2 * d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
 
 
 # ------------------------------------------------------------------ next-1: time alignment on the device
@@ -686,7 +750,7 @@ def _random_outage_batch(nb, N, seed):
 
 @pytest.mark.parametrize("N", [300, 777, 4099])
 def test_random_outage_patterns_every_kernel_vs_oracle(B, orc, N):
-    """Outage structure stress: every K4 build (both layouts and all opt-in variants) against the dense oracle on tracks with up to
+    """Outage structure stress: every K4 kernel (both layouts, both routes of the time-major one) against the dense oracle on tracks with up to
     four outages of 1..N/2 poses, NaN fixes, sharp-turn recoveries, outages at both ends -- positions inside the gate, status bits
     and therefore every start / recovery / sharp-turn / RTS decision exact."""
     nb = 192 if N < 1000 else 48                      # N = 4099: outages of up to 2 049 poses, i.e. carried over 32 chunks
@@ -694,21 +758,12 @@ def test_random_outage_patterns_every_kernel_vs_oracle(B, orc, N):
     po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
     for bit in (1, 2, 4, 8):                          # outage, RTS, sharp-turn recovery, ended-in-outage all occur in the batch
         assert (sto & bit).any(), bit
-    ctx = B.context()
-    builds = [("default", None, 0), ("time-major lane kernel", None, 1), ("wave_ppl", 2, 0), ("wave_ppl", 5, 0), ("ekf_variant", 8, 0), ("seg_kernel", 1, 0)]
-    if N > 1024:
-        builds = [b for b in builds if b[0] != "ekf_variant"]       # the block kernel takes N <= 1024
-    for key, val, layout in builds:
-        batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
-        if val is not None:
-            ctx.set_option(key, val)
-        try:
+    for layout in LAYOUTS:                            # wave kernel, time-major via the wave kernel, time-major lane kernel
+        with route(B, layout) as lay:
+            batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=lay)
             p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
-        finally:
-            if val is not None:
-                ctx.set_option(key, 0)
-        np.testing.assert_array_equal(st, sto, err_msg=f"{key} {val}")
-        assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL, (key, val, np.abs(p - po).max())
+        np.testing.assert_array_equal(st, sto, err_msg=f"layout {layout}")
+        assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL, (layout, np.abs(p - po).max())
 
 
 def test_gps_ransac_filter_vs_reference_goldens(E, golden):

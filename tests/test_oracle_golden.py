@@ -102,6 +102,15 @@ def test_c1_pipeline(golden, tag):
     np.testing.assert_allclose(q, g["ekf_quat"], atol=Q_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["kitti04gps", "combined"])
+def test_error_metric_vs_reference(golden, tag):
+    """The oracle's restatement of the reference's error metric (Q15, :1013-1033) against the reference's own numbers."""
+    g, k = golden(f"c1_{tag}.npz"), golden("kat_bundled.npz")
+    for traj, ref in ((g["sim3_pos"], g["err_sim3"]), (g["ekf_pos"], g["err_ekf"])):
+        r = orc.evaluate_trajectory_errors(k["ts"], traj, g["aligned"], g["valid"])
+        np.testing.assert_allclose([r["mean"], r["median"], r["rmse"]], ref, atol=1e-10, rtol=0)
+
+
 def test_c1_ransac_draws_match_legacy_rng(golden):
     g = golden("c1_kitti04gps.npz")
     np.random.seed(0)
