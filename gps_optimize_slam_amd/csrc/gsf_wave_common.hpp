@@ -421,9 +421,10 @@ __device__ __forceinline__ void wave_variance_helper(const WaveArgs& a, const Ek
 // PREVAR (two-wave kernel): the variances come from LDS (pv, written by wave_variance_helper) once the block barrier after the
 // fit has been passed; everything else is identical, so the two kernels produce the same bits.
 // SMALLBATCH: the cold blocks are inlined (no far calls; ~27 more registers, which only matter when three waves per SIMD do).
-template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false>
+// RINGS / ring_slot: main waves per block (each owns one slice of the lane-private LDS ring).
+template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1>
 __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
-                                                 const double* pv = nullptr, const int pv_stride = 0)
+                                                 const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0)
 {
     GSF_STAMP(0);
     int64_t base, N; traj_span(a, b, base, N);
@@ -436,7 +437,8 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
 
-    __shared__ double gsf_ring[2][6][64];                                // lane-private: rows + P_f of the last two open-outage chunks
+    __shared__ double gsf_ring_all[RINGS][2][6][64];                     // lane-private: rows + P_f of the last two open-outage chunks
+    double (*gsf_ring)[6][64] = gsf_ring_all[RINGS > 1 ? ring_slot : 0];
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
     ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     Vec3 p0; Quat q0; int32_t fit = 0;

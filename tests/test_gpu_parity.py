@@ -843,21 +843,26 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
-def test_two_wave_pipeline_kernel_is_bit_identical(B):
-    """The two-wave pipeline kernel (helper wave computes every chunk's variances during the fit) runs the same functions on the
-    same operands as the one-wave kernel: identical bits, so the automatic choice by batch size cannot change results."""
-    for N in (65, 271, 640):
-        batch = B.TrajectoryBatch.synthetic(500, N, layout=0, seed=31)
+def test_two_wave_pipeline_kernels_are_bit_identical(B):
+    """The helper-wave builds of the fused pipeline (a second wave computes every chunk's variances during the fit; 128-thread
+    blocks = duo_kernel 1, four trajectories per 512-thread block = duo_kernel 2) run the same functions on the same operands as
+    the one-wave kernel: identical bits, so the automatic choice by batch size cannot change results (shard invariance)."""
+    for N, nb in ((65, 500), (271, 1001), (384, 203), (640, 500)):
+        batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=31)
         batch.quat[7, N // 3] = 0.0                                     # one track on the generic (bad quaternion) path
         batch.quat[9, 0] = 0.0                                          # pose-0 quaternion invalid: the main wave leaves right after the fit
         batch.valid[11, :] = 0                                          # no usable fix at all: fit is None, same early exit
         res = {}
-        for duo in (0, 1):
+        modes = (0, 1, 2) if N <= 384 else (0, 1)
+        for duo in modes:
             B.context().set_option("duo_kernel", duo)
             try:
                 out, R, t, s = B.fuse_pipeline_batch(batch)
                 res[duo] = out.host_traj_major() + (R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy())
             finally:
                 B.context().set_option("duo_kernel", -1)
-        for x0, x1 in zip(res[0], res[1]):
-            np.testing.assert_array_equal(x0, x1)
+        out, R, t, s = B.fuse_pipeline_batch(batch)                     # automatic choice
+        res["auto"] = out.host_traj_major() + (R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy())
+        for key in list(modes[1:]) + ["auto"]:
+            for x0, x1 in zip(res[0], res[key]):
+                np.testing.assert_array_equal(x0, x1, err_msg=f"N={N} B={nb} duo={key}")

@@ -8,7 +8,7 @@ from gps_optimize_slam_amd import batch as B
 
 nb, n = int(sys.argv[1]), int(sys.argv[2])
 pipe = len(sys.argv) > 3
-B.context().set_option("duo_kernel", 0)
+B.context().set_option("duo_kernel", int(os.environ.get("DUO", "0")))
 bj = B.TrajectoryBatch.synthetic(nb, n, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
 oj = B.FusedPoses(bj.layout, nb, n, "cuda")
 oj.status = torch.zeros(2 * nb, dtype=torch.int32, device="cuda")
