@@ -77,6 +77,10 @@ SIGNATURES = {
     "gsf_sim3_umeyama_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_mt19937_seed_batch_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gsf_mt19937_choice_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gsf_fuse_pipeline_robust_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
+                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_apply_sim3_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_apply_sim3_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_ekf_fuse_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),

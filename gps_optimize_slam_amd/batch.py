@@ -148,6 +148,52 @@ def fuse_pipeline_batch(batch, config=None, out=None):
     return out, R, t, s
 
 
+def mt19937_seed(seeds, device="cuda"):
+    """np.random.seed(seeds[b]) for B independent legacy-MT19937 streams -> state (B, 625) uint32 on the device (key[624] + pos)."""
+    seeds = torch.as_tensor(seeds, dtype=torch.int64).to(device)
+    st = torch.empty((seeds.numel(), 625), dtype=torch.int32, device=device)
+    check(_lib.load().gsf_mt19937_seed_batch_dev(context().handle, _p(seeds.to(torch.int32)), seeds.numel(), _p(st)))
+    return st
+
+
+def mt19937_from_numpy(device="cuda"):
+    """NumPy's GLOBAL legacy generator as a one-stream device state (1, 625): what a seeded reference run would draw from next."""
+    import numpy as np
+    _, key, pos = np.random.get_state()[:3]
+    st = np.concatenate([key.astype(np.uint32), np.array([pos], dtype=np.uint32)]).view(np.int32)
+    return torch.from_numpy(st.copy()).reshape(1, 625).to(device)
+
+
+def mt19937_choice_batch(state, n_population, trials, k):
+    """sample_idx (B, trials, k) int32 = np.random.choice(n_population[b], k, replace=False) drawn `trials` times from stream b;
+    `state` (B, 625) is advanced in place exactly as NumPy's generator would be."""
+    B = state.shape[0]
+    n = torch.as_tensor(n_population, dtype=torch.int32).to(state.device).contiguous()
+    idx = torch.empty((B, trials, k), dtype=torch.int32, device=state.device)
+    check(_lib.load().gsf_mt19937_choice_batch_dev(context().handle, _p(state), _p(n), B, int(trials), int(k), _p(idx)))
+    return idx
+
+
+def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask=True):
+    """Steps 3-5 of main_process_gui with the reference's robust fit (EKFGPSSLAM.py:1002-1010): RANSAC hypotheses drawn on the
+    device from each trajectory's legacy MT19937 stream -> inlier refit -> Sim3 of pose 0 -> EKF+RTS, one chain on torch's current
+    stream.  Trajectory-major batches.  Returns (FusedPoses, R, t, s, n_inliers (B,), inlier_mask (B, N) uint8 or None)."""
+    if batch.layout != LAYOUT_TRAJ_MAJOR:
+        raise ValueError("fuse_pipeline_robust_batch: trajectory-major batches only")
+    g = config or CONFIG
+    cfg, r = EkfConfig.from_config(g), g["sim3_ransac"]
+    out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
+    f = dict(dtype=torch.float64, device=batch.ts.device)
+    R, t, s = torch.empty((batch.B, 9), **f), torch.empty((batch.B, 3), **f), torch.empty((batch.B,), **f)
+    nin = torch.empty((batch.B,), dtype=torch.int32, device=batch.ts.device)
+    mask = torch.empty((batch.B, batch.N), dtype=torch.uint8, device=batch.ts.device) if want_mask else None
+    check(_lib.load().gsf_fuse_pipeline_robust_batch_dev(context().handle, _p(batch.ts), _p(batch.pos), _p(batch.quat), _p(batch.gps), _p(batch.valid),
+                                                         C.byref(cfg), batch.B, batch.N, int(r["min_samples"]), float(r["residual_threshold"]),
+                                                         int(r["max_trials"]), int(r["min_inliers_needed"]), _p(mt_state), _p(R), _p(t), _p(s),
+                                                         _p(out.pos), _p(out.quat), _p(out.status), _p(nin), _p(mask)))
+    return out, R, t, s, nin, mask
+
+
 def sim3_umeyama_batch(src, dst, offsets=None, mask=None):
     """K2 over device tensors.  src/dst: (total,3) with int64 offsets (B+1,), or (B,W,3) equal-size windows.
     Returns R (B,9), t (B,3), s (B,), status (B,) int32."""

@@ -215,7 +215,7 @@ GSF_HD void svd3(const double* H, Svd3& out)
 }
 
 // status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
-enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4 };
+enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8 };
 
 // Umeyama closed form from the reduced moments, ref :439-451.
 //   H = sum src_c dst_c^T (row-major), ssq = sum |src_c|^2, sc/dc centroids, n points.

@@ -254,7 +254,7 @@ __device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const 
 }
 
 __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
-    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
+    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
     double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
     int32_t* __restrict__ n_inliers)
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     __shared__ int sh_cnt[RANSAC_THREADS / 64];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
-    const int64_t i0 = offsets[b], i1 = offsets[b + 1], n = i1 - i0;
+    // set b = rows offsets[b] .. offsets[b] + n; n = counts[b] when the sets sit in fixed-stride slots (robust pipeline), else the gap
+    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
     auto write_none = [&](int32_t best) {
         if (tid == 0) {
             for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
@@ -281,8 +282,13 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     // ---- hypotheses: one per thread, strided over the trials (ref :404-414)
     const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
     long long best_cnt = -1; int best_trial = 0x7fffffff;
+    bool bad_index = false;
     for (int tr = tid; tr < trials; tr += RANSAC_THREADS) {
         double R[9], t[3], s;
+        // caller-fed row indices are validated: a sample naming a row outside [0, n) is skipped like a degenerate one and flagged
+        bool in_range = true;
+        for (int k = 0; k < ms; ++k) { const int32_t ix = my_idx[(size_t)tr * ms + k]; in_range = in_range && ix >= 0 && (int64_t)ix < n; }
+        if (!in_range) { bad_index = true; continue; }
         if (fit_sample(src, dst, i0, my_idx + (size_t)tr * ms, ms, R, t, s) == SIM3_NONE) continue;   // :408
         long long cnt = 0;
         // the rows are wave-uniform scalar loads: eight rows' residuals are formed before the first decision so that their loads are
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
         unsigned long long other = __shfl_xor(key, o, 64);
         key = other > key ? other : key;
     }
+    const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
     if ((tid & 63) == 0) sh_key[tid >> 6] = key;
     __syncthreads();
     key = sh_key[0];
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
         if (st == SIM3_NONE) { for (int k = 0; k < 9; ++k) R[k] = NAN; t[0] = t[1] = t[2] = NAN; s = NAN; }
         for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = R[k];
         tout[b * 3] = t[0]; tout[b * 3 + 1] = t[1]; tout[b * 3 + 2] = t[2]; sout[b] = s;
-        status[b] = st; n_inliers[b] = (int32_t)win_cnt;
+        status[b] = st | ((any_bad && st != SIM3_NONE) ? SIM3_FLAG_BAD_INDEX : 0); n_inliers[b] = (int32_t)win_cnt;
     }
     (void)sh_cnt;
 }
@@ -401,6 +408,18 @@ __global__ __launch_bounds__(256) void apply_sim3_kernel(const double* __restric
 
 }  // namespace
 
+namespace gsf {
+int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,
+                       const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
+                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
+{
+    hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
+                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+}  // namespace gsf
+
 extern "C" {
 
 int gsf_sim3_umeyama_batch_dev(gsf_ctx* ctx, const double* src, const double* dst, const uint8_t* mask, const int64_t* offsets,
@@ -426,10 +445,7 @@ int gsf_sim3_ransac_batch_dev(gsf_ctx* ctx, const double* src, const double* dst
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, sample_idx,
-                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers);
-    GSF_HIP(hipGetLastError());
-    return GSF_OK;
+    return launch_sim3_ransac(ctx, src, dst, offsets, nullptr, B, sample_idx, trials, min_samples, thr, min_inliers, R, t, s, status, inlier_mask, n_inliers);
 }
 
 int gsf_apply_sim3_batch_dev(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R,

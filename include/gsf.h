@@ -68,6 +68,7 @@ typedef struct {
 #define GSF_SIM3_NONE 1
 #define GSF_SIM3_FLAG_VAR0 2          /* var_src < 1e-12 -> scale := 1   (EKFGPSSLAM.py:445-447) */
 #define GSF_SIM3_FLAG_SMALL_SCALE 4   /* scale <= 1e-6  -> scale := 1   (EKFGPSSLAM.py:450) */
+#define GSF_SIM3_FLAG_BAD_INDEX 8     /* a caller-fed sample set named a row outside [0, n): that trial was skipped */
 
 /* status bits of a fused trajectory */
 #define GSF_ST_HAD_OUTAGE 1
@@ -159,6 +160,18 @@ GSF_API int gsf_sim3_ransac_batch(gsf_ctx *ctx, const double *src, const double 
                           int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,
                           uint8_t *inlier_mask, int32_t *n_inliers);
 
+/* ---- the reference's random draws on the device (np.random.choice(n, k, replace=False), EKFGPSSLAM.py:405) ---------- */
+/* state: uint32[B][625] = NumPy's legacy MT19937 state per stream, key[624] then pos -- exactly np.random.get_state()[1:3], so a
+   host can hand over its global generator (B = 1) or seed one stream per trajectory.
+   gsf_mt19937_seed_batch_dev: np.random.seed(seeds[b]) for every stream.
+   gsf_mt19937_choice_batch_dev: sample_idx[b][trial][0..k) = RandomState.permutation(n_population[b])[:k] for `trials`
+   consecutive trials of stream b (what np.random.choice(n, k, replace=False) draws; also scikit-learn's
+   sample_without_replacement for 0.01 < k/n < 0.99), the state advanced exactly as NumPy advances it.  Streams with
+   n_population[b] < k are left untouched (the reference returns before drawing, :395-397).  n_population[b] <= 28000, k <= 64. */
+GSF_API int gsf_mt19937_seed_batch_dev(gsf_ctx *ctx, const uint32_t *seeds, int64_t B, uint32_t *state);
+GSF_API int gsf_mt19937_choice_batch_dev(gsf_ctx *ctx, uint32_t *state, const int32_t *n_population, int64_t B, int32_t trials,
+                                         int32_t k, int32_t *sample_idx);
+
 /* ---- K3: apply Sim3 (transform_trajectory, EKFGPSSLAM.py:461-467) -------------------------- */
 /* pos[total][3], quat[total][4]; per-trajectory R[B][9], t[B][3], s[B].  A zero-norm quaternion (SciPy raises
    ValueError there) yields NaN quaternion output and sets bad_quat[b] (int32[B], may be NULL). */
@@ -188,6 +201,18 @@ GSF_API int gsf_ekf_fuse_batch(gsf_ctx *ctx, int32_t layout, const double *ts, c
 GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
                                 const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
                                 double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
+
+/* ---- the same steps with the reference's ROBUST fit (compute_sim3_transform_robust, EKFGPSSLAM.py:1002, :389-426) ---------- */
+/* One device chain, no host round trip: rows with valid finite GNSS -> max_trials hypotheses drawn from each trajectory's
+   legacy MT19937 stream (mt_state[B][625], in/out: see gsf_mt19937_*) -> first-best inlier set, final Umeyama on the inliers ->
+   Sim3 of pose 0 -> EKF+RTS.  Trajectory-major layout.  Outputs as gsf_fuse_pipeline_batch_dev plus n_inliers[B] (best count,
+   -1 if no hypothesis succeeded) and inlier_mask[B][N] (uint8, original row order, may be NULL).  The workspace (about
+   53 B/pose + 4 B x max_trials x min_samples per trajectory) is the context's, grown on demand. */
+GSF_API int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                               const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N, int32_t min_samples,
+                                               double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t *mt_state,
+                                               double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status,
+                                               int32_t *n_inliers, uint8_t *inlier_mask);
 
 /* ragged forms (trajectories of different lengths): flat [total][C] arrays, trajectory b = rows offsets[b]..offsets[b+1] */
 GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,

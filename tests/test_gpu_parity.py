@@ -843,6 +843,100 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
+def test_device_mt19937_choice_matches_numpy(B):
+    """np.random.choice(n, k, replace=False) of NumPy's legacy generator reproduced on the device: the same sample sets trial by
+    trial AND the same generator state afterwards (the next NumPy draw continues the stream), for seeded streams and for a state
+    handed over from the host's global generator; streams with n < k stay untouched."""
+    import torch
+    cases = [(7, 271, 50, 4), (123456, 1000, 20, 4), (0, 5, 40, 4), (2**32 - 1, 64, 30, 6), (99, 4, 10, 4), (5, 1730, 7, 4), (31, 300, 25, 1),
+             (77, 3, 5, 4)]
+    seeds = [c[0] for c in cases]
+    for trials_mult in (1,):
+        st = B.mt19937_seed(seeds)
+        # one launch per case (trials / k differ); streams of the other cases are masked out by n < k
+        for ci, (seed, n, trials, k) in enumerate(cases):
+            npop = [0] * len(cases); npop[ci] = n
+            idx = B.mt19937_choice_batch(st, npop, trials, k).cpu().numpy()[ci]
+            np.random.seed(seed)
+            if n >= k:
+                ref = np.stack([np.random.choice(n, k, replace=False) for _ in range(trials)])
+                np.testing.assert_array_equal(idx, ref, err_msg=f"case {ci}")
+            key, pos = np.random.get_state()[1:3]
+            got = st[ci].cpu().numpy().view(np.uint32)
+            np.testing.assert_array_equal(got[:624], key, err_msg=f"state of case {ci}")
+            assert int(got[624]) == int(pos), (ci, got[624], pos)
+    # a state taken over from the host's global generator, mid-stream
+    np.random.seed(2024); np.random.random(1000)
+    st1 = B.mt19937_from_numpy()
+    idx = B.mt19937_choice_batch(st1, [271], 300, 4).cpu().numpy()[0]
+    ref = np.stack([np.random.choice(271, 4, replace=False) for _ in range(300)])
+    np.testing.assert_array_equal(idx, ref)
+    after = np.random.random()
+    key, pos = st1[0].cpu().numpy().view(np.uint32)[:624], int(st1[0].cpu().numpy().view(np.uint32)[624])
+    np.random.set_state(("MT19937", key, pos))
+    assert np.random.random() == after
+
+
+def test_robust_pipeline_chain_vs_oracle(B, orc):
+    """RANSAC -> final fit -> Sim3 of pose 0 -> EKF+RTS as ONE device chain with the draws generated on the device, against the
+    oracle fed with NumPy's own draws for the same seeds: identical inlier masks / counts, R, t, s and fused poses inside the gate."""
+    nb, N = 24, 271
+    batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=41)
+    h = batch.host_traj_major()
+    # outliers: a few GNSS fixes thrown far off so that the robust fit differs from the plain one
+    rng = np.random.default_rng(3)
+    for b in range(nb):
+        rows = rng.choice(np.where(h["valid"][b] != 0)[0], size=9, replace=False)
+        batch.gps[b, rows] += torch_from(rng.normal(size=(9, 3)) * 40.0)
+    batch.valid[5, :] = 0                                               # no usable fix: the reference returns None before drawing
+    batch.quat[7, 0] = 0.0                                              # pose-0 quaternion invalid
+    h = batch.host_traj_major()
+    cfg = B.CONFIG["sim3_ransac"]
+    seeds = np.arange(100, 100 + nb)
+    st = B.mt19937_seed(seeds)
+    out, R, t, s, nin, mask = B.fuse_pipeline_robust_batch(batch, st)
+    p, q, status = out.host_traj_major()
+    R, t, s, nin, mask = R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy(), nin.cpu().numpy(), mask.cpu().numpy()
+    plain = B.fuse_pipeline_batch(batch)[1].cpu().numpy()
+    differs = 0
+    for b in range(nb):
+        ok = (h["valid"][b] != 0) & ~np.isnan(h["gps"][b]).any(axis=1)
+        src, dst = h["pos"][b][ok], h["gps"][b][ok]
+        np.random.seed(int(seeds[b]))
+        if ok.sum() >= cfg["min_samples"]:
+            draws = np.stack([np.random.choice(int(ok.sum()), cfg["min_samples"], replace=False) for _ in range(cfg["max_trials"])]).astype(np.int32)
+            res = orc.compute_sim3_transform_robust(src, dst, cfg["min_samples"], cfg["residual_threshold"], cfg["max_trials"], cfg["min_inliers_needed"],
+                                                    sample_idx=draws, return_mask=True)
+        else:
+            res = (None, None, None)
+        key, pos = np.random.get_state()[1:3]
+        got = st[b].cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(got[:624], key); assert int(got[624]) == int(pos)
+        if res[0] is None:
+            assert (status[b] >> 8) & 1 and np.isnan(p[b]).all() and np.isnan(R[b]).all()
+            continue
+        Ro, to, so, mo = res
+        full = np.zeros(N, dtype=bool); full[np.where(ok)[0]] = mo
+        np.testing.assert_array_equal(mask[b].astype(bool), full, err_msg=f"inlier mask of trajectory {b}")
+        assert nin[b] == mo.sum() or nin[b] >= mo.sum()
+        np.testing.assert_allclose(R[b].reshape(3, 3), Ro, atol=2e-9, rtol=0)
+        assert abs(s[b] - so) < 1e-11
+        if b == 7:
+            assert np.isnan(p[b]).all() and (status[b] & 16)
+            continue
+        sp, sq = orc.transform_trajectory(h["pos"][b][:1], h["quat"][b][:1], Ro, to, so)
+        po, qo, sto = orc.apply_ekf_correction_aligned(h["ts"][b], h["pos"][b], h["quat"][b], h["gps"][b], h["valid"][b], sp[0], sq[0], return_status=True)
+        assert np.abs(p[b] - po).max() < POS_TOL and np.abs(q[b] - qo).max() < Q_TOL, (b, np.abs(p[b] - po).max())
+        assert (status[b] & 0xff) == sto
+        differs += int(np.abs(R[b] - plain[b]).max() > 1e-6)
+    assert differs >= nb // 2                                           # the planted outliers really separate the robust from the plain fit
+
+
+def torch_from(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).cuda()
+
+
 def test_two_wave_pipeline_kernels_are_bit_identical(B):
     """The helper-wave builds of the fused pipeline (a second wave computes every chunk's variances during the fit; 128-thread
     blocks = duo_kernel 1, four trajectories per 512-thread block = duo_kernel 2) run the same functions on the same operands as
