@@ -578,6 +578,21 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         o = B.FusedPoses(bt.layout, 1000, 271, dev)
         extra["c2_time_major_pipeline_ms"] = timed(lambda: B.fuse_pipeline_batch(bt, out=o), 50)
         del bt, o
+        # the path from the geodetic GNSS log (K1 -> time alignment -> fit -> EKF, one device chain) and the robust chain (device-side
+        # legacy-MT19937 draws -> RANSAC -> inlier refit -> Sim3 of pose 0 -> EKF), both at the C2 shape
+        gb = B.GeodeticBatch.synthetic(1000, 271, seed=SEED)
+        og = B.FusedPoses(B.LAYOUT_TRAJ_MAJOR, 1000, 271, dev)
+        ms_g = timed(lambda: B.fuse_from_geodetic(gb, out=og), 50)
+        extra["geodetic_chain_c2"] = {"ms": ms_g, "poses_per_s": 271e3 / ms_g * 1e3, "gnss_fixes": int(gb.gps_t.numel()),
+                                      "stages": "gsf_gps_rows_to_utm_batch_dev -> gsf_time_align_batch_dev -> gsf_fuse_pipeline_batch_dev"}
+        del gb, og
+        bt = B.TrajectoryBatch.synthetic(1000, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
+        o = B.FusedPoses(bt.layout, 1000, 271, dev)
+        st0 = B.mt19937_seed(np.arange(1000))
+        ms_r = timed(lambda: B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False), 5)
+        extra["robust_chain_c2"] = {"ms": ms_r, "poses_per_s": 271e3 / ms_r * 1e3, "max_trials": B.CONFIG["sim3_ransac"]["max_trials"],
+                                    "stages": "compact -> mt19937 choice (1000 x permutation(n)[:4] per trajectory) -> K2b -> Sim3(pose 0) -> K4"}
+        del bt, o, st0
         extra["c1_drop_in"] = c1_latency(np)
     return extra
 

@@ -71,12 +71,14 @@ SIGNATURES = {
     "gsf_utm_inverse_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gsf_utm_forward": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "gsf_utm_inverse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "gsf_gps_rows_to_utm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_geodetic_to_enu_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_ransac_poly_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_sim3_ransac_mt_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_mt19937_seed_batch_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gsf_mt19937_choice_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gsf_fuse_pipeline_robust_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
@@ -103,6 +105,7 @@ SIGNATURES = {
     "gsf_allgather_poses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64]),
     "gsf_transpose_to_time_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsf_transpose_to_traj_major_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32]),
+    "gsf_synth_geodetic_batch_dev": (C.c_int, [_vp, C.c_uint64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_synth_batch_dev": (C.c_int, [_vp, _i32, C.c_uint64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -93,6 +93,54 @@ class TrajectoryBatch:
         return {k: getattr(t, k).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
 
 
+class GeodeticBatch:
+    """B trajectories x N poses whose GNSS side is still what the reference's loader reads (load_gps_data, EKFGPSSLAM.py:258):
+    a ragged log of fixes with their own stamps, rows (lat deg, lon deg, alt m).  Input of fuse_from_geodetic()."""
+
+    def __init__(self, B, N, ts, pos, quat, gps_offsets, gps_t, gps_llh, max_fixes):
+        self.B, self.N, self.ts, self.pos, self.quat = int(B), int(N), ts, pos, quat
+        self.gps_offsets, self.gps_t, self.gps_llh, self.max_fixes = gps_offsets, gps_t, gps_llh, int(max_fixes)
+        self.slam_offsets = torch.arange(0, (self.B + 1) * self.N, self.N, dtype=torch.int64, device=ts.device)
+
+    @classmethod
+    def synthetic(cls, B, N, seed=20250523, traj0=0, device="cuda"):
+        """Deterministic KITTI-04-shaped trajectories with a geodetic GNSS log around (49.0336 N, 8.3950 E)."""
+        L, h = _lib.load(), context().handle
+        f = dict(dtype=torch.float64, device=device)
+        ts, pos, quat = torch.empty((B, N), **f), torch.empty((B, N, 3), **f), torch.empty((B, N, 4), **f)
+        counts = torch.empty((B,), dtype=torch.int64, device=device)
+        check(L.gsf_synth_geodetic_batch_dev(h, C.c_uint64(seed), int(traj0), B, N, None, None, None, _p(counts), None, None, None))
+        offs = torch.zeros((B + 1,), dtype=torch.int64, device=device)
+        offs[1:] = torch.cumsum(counts, 0)
+        total, mx = int(offs[-1].item()), int(counts.max().item())      # sizing of the ragged log (host values, once per batch)
+        gps_t, gps_llh = torch.empty((total,), **f), torch.empty((total, 3), **f)
+        check(L.gsf_synth_geodetic_batch_dev(h, C.c_uint64(seed), int(traj0), B, N, _p(ts), _p(pos), _p(quat), None, _p(offs), _p(gps_t), _p(gps_llh)))
+        return cls(B, N, ts, pos, quat, offs, gps_t, gps_llh, mx)
+
+
+def fuse_from_geodetic(gb, config=None, out=None):
+    """The whole path from the geodetic GNSS log on the device, no host round trip: geodesy slice (mask, zone pick, UTM forward,
+    [E, N, alt] rows; ref :258-271) -> dynamic_time_alignment to the SLAM stamps (ref :325-387, :971) -> Umeyama on the valid rows
+    -> Sim3 of pose 0 -> EKF+RTS (ref :1002-1010, plain fit).  Returns (FusedPoses, R, t, s, aux) with aux = dict(zone, south,
+    utm_rows, aligned, valid)."""
+    g = config or CONFIG
+    cfg = EkfConfig.from_config(g)
+    L, h, dev = _lib.load(), context().handle, gb.ts.device
+    f = dict(dtype=torch.float64, device=dev)
+    utm = torch.empty_like(gb.gps_llh)
+    zone, south = torch.empty((gb.B,), dtype=torch.int32, device=dev), torch.empty((gb.B,), dtype=torch.int32, device=dev)
+    check(L.gsf_gps_rows_to_utm_batch_dev(h, _p(gb.gps_llh), _p(gb.gps_offsets), gb.B, _p(utm), _p(zone), _p(south)))
+    aligned = torch.empty((gb.B, gb.N, 3), **f)
+    valid = torch.empty((gb.B, gb.N), dtype=torch.uint8, device=dev)
+    check(L.gsf_time_align_batch_dev(h, _p(gb.ts), _p(gb.slam_offsets), _p(gb.gps_t), _p(utm), _p(gb.gps_offsets), gb.B, max(2, gb.max_fixes),
+                                     float(g["time_alignment"]["max_gps_gap_threshold"]), _p(aligned), _p(valid), None))
+    out = out or FusedPoses(LAYOUT_TRAJ_MAJOR, gb.B, gb.N, dev)
+    R, t, s = torch.empty((gb.B, 9), **f), torch.empty((gb.B, 3), **f), torch.empty((gb.B,), **f)
+    check(L.gsf_fuse_pipeline_batch_dev(h, LAYOUT_TRAJ_MAJOR, _p(gb.ts), _p(gb.pos), _p(gb.quat), _p(aligned), _p(valid), C.byref(cfg), gb.B, gb.N,
+                                        _p(R), _p(t), _p(s), _p(out.pos), _p(out.quat), _p(out.status)))
+    return out, R, t, s, {"zone": zone, "south": south, "utm_rows": utm, "aligned": aligned, "valid": valid}
+
+
 class FusedPoses:
     """Fused poses of a batch.  pos and quat are views of ONE allocation `buf` = [pos | quat] (7 doubles per pose), so the
     multi-GPU collect is a single all-gather of `buf`.  `buf` may be a caller-provided slice of a larger arena."""

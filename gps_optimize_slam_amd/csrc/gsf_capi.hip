@@ -295,6 +295,41 @@ int gsf_sim3_ransac_batch(gsf_ctx* ctx, const double* src, const double* dst, co
     ST_RUN(gsf_sim3_ransac_batch_dev(ctx, dsrc, ddst, doff, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni));
 }
 
+// compute_sim3_transform_robust with the draws made on the device: mt_state[B][625] (host, in/out) is NumPy's legacy generator state
+int gsf_sim3_ransac_mt_batch(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, int64_t B, uint32_t* mt_state,
+                             int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t, double* s,
+                             int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
+{
+    GSF_REQUIRE(ctx && offsets && B >= 0 && B <= 0x7fffffff && mt_state && R && t && s && status && inlier_mask && n_inliers, "bad arguments");
+    GSF_REQUIRE(trials >= 0 && trials <= (1 << 20) && min_samples >= 1 && min_samples <= 8, "bad trials / min_samples (1..8)");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (src && dst)), "bad offsets / NULL points");
+    std::vector<int32_t> counts((size_t)B);
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t n = offsets[b + 1] - offsets[b];
+        GSF_REQUIRE(n >= 0 && n <= 28000, "a point set has more than 28000 rows (device-side draws) or negative length");
+        counts[(size_t)b] = (int32_t)n;
+    }
+    const size_t nidx = (size_t)B * (size_t)trials * (size_t)min_samples;
+    ST_BEGIN((size_t)total * 49 + (size_t)(B + 1) * 8 + (size_t)B * (625 * 8 + 4 + 112) + nidx * 4, 14);
+    const double* dsrc = st.in(src, (size_t)total * 3); const double* ddst = st.in(dst, (size_t)total * 3);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    const int32_t* dcnt = st.in(counts.data(), (size_t)B);
+    const uint32_t* dst_in = st.in(mt_state, (size_t)B * 625);
+    uint32_t* dstate = st.out(mt_state, (size_t)B * 625);
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    int32_t* dst_ = st.out(status, (size_t)B); int32_t* dni = st.out(n_inliers, (size_t)B);
+    uint8_t* dmask = st.out(inlier_mask, (size_t)total);
+    int32_t* didx = st.tmp<int32_t>(nidx + 1);
+    int rc = st.upload();
+    if (rc) return rc;
+    GSF_HIP(hipMemcpyAsync(dstate, dst_in, (size_t)B * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (trials > 0 && (rc = launch_mt_choice(ctx, dstate, dcnt, B, trials, min_samples, didx))) return rc;
+    if ((rc = launch_sim3_ransac(ctx, dsrc, ddst, doff, nullptr, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni))) return rc;
+    return st.finish();
+}
+
 int gsf_apply_sim3_batch(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R,
                          const double* t, const double* s, double* pos_out, double* quat_out, int32_t* bad_quat)
 {

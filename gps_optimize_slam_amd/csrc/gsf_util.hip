@@ -141,6 +141,73 @@ __global__ __launch_bounds__(64) void synth_kernel(uint64_t seed, int64_t traj0,
     }
 }
 
+// The same trajectories with the GNSS side as a RAGGED geodetic log (what load_gps_data reads, ref :258): fix k of trajectory j is
+// taken at the SLAM stamp + a per-trajectory receiver phase in (0, 0.03) s on the true path (linear between the neighbouring
+// poses), mapped to (lat, lon, alt) about (49.0336 N, 8.3950 E, 112 m) by the tangent-plane metric at that latitude -- two
+// constants, no libm, so a host generator can reproduce the values -- plus the same 0.45 m noise; fixes inside the outage plan are
+// ABSENT (the log just has a gap > max_gps_gap_threshold), the planted UTM frame is replaced by true geography.
+// counts[j] fixes per trajectory (pass 1, WRITE = false), rows at gps_offsets[j] (pass 2).
+constexpr double SYN_DEG_PER_M_NORTH = 8.991965674724778e-06, SYN_DEG_PER_M_EAST = 1.3675669825622133e-05;
+template <bool WRITE>
+__global__ __launch_bounds__(64) void synth_geodetic_kernel(uint64_t seed, int64_t traj0, int64_t B, int64_t N, double* __restrict__ ts,
+                                                            double* __restrict__ pos, double* __restrict__ quat, int64_t* __restrict__ counts,
+                                                            const int64_t* __restrict__ gps_offsets, double* __restrict__ gps_t,
+                                                            double* __restrict__ gps_llh)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const Idx<GSF_LAYOUT_TRAJ_MAJOR> ix{ B, N };
+    const uint64_t j = (uint64_t)(traj0 + b);
+    const double scale = uni(0.9, 1.1, seed, j, TRAJ, 0);
+    const double heading = uni(-1.0, 1.0, seed, j, TRAJ, 1);            // tan(heading/2) of the track's course over ground
+    const double ch = (1.0 - heading * heading) / (1.0 + heading * heading), sh = 2.0 * heading / (1.0 + heading * heading);
+    const double a1 = uni(-0.15, 0.15, seed, j, TRAJ, 8), a2 = uni(-0.15, 0.15, seed, j, TRAJ, 9);
+    const double phase = uni(0.004, 0.03, seed, j, TRAJ, 14);
+    const double T = 0.10411 * (double)(N > 1 ? N - 1 : 1);
+    const double kind = u01(seed, j, TRAJ, 10);
+    int64_t o0 = -1, o1 = -1;
+    if (kind < 0.10) {
+        int64_t L = 53 + (int64_t)(u01(seed, j, TRAJ, 11) * 63.0);
+        if (L > N / 3) L = N / 3;
+        const int64_t room = N - L - 40;
+        o0 = room > 0 ? 20 + (int64_t)(u01(seed, j, TRAJ, 12) * (double)room) : N / 3;
+        o1 = o0 + L;
+    } else if (kind < 0.12) { o0 = 0; o1 = 10 + (int64_t)(u01(seed, j, TRAJ, 11) * 31.0); if (o1 > N / 2) o1 = N / 2; }
+    else if (kind < 0.14) { int64_t K = 10 + (int64_t)(u01(seed, j, TRAJ, 11) * 31.0); if (K > N / 2) K = N / 2; o0 = N - K; o1 = N; }
+    if (!WRITE) { counts[b] = (N - 1) - ((o1 > o0) ? ((o1 < N - 1 ? o1 : N - 1) - o0) : 0); return; }
+    int64_t w = gps_offsets[b];
+    double t_prev = 0.0;
+    Vec3 p{ 0.0, 0.0, 0.0 }, p_prev{ 0.0, 0.0, 0.0 };
+    for (int64_t i = 0; i < N; ++i) {
+        const double t = (i == 0) ? 0.0 : (double)i * 0.10411 + uni(-0.002, 0.002, seed, j, (uint64_t)i, 0);
+        const double tau = t / T;
+        const double u = a1 * tau + a2 * tau * tau;
+        const double ru = 1.0 / (1.0 + u * u);
+        p_prev = p;
+        if (i > 0) {
+            const double step = 14.0 * (t - t_prev);
+            p.x += step * (2.0 * u * ru); p.y += step * 0.002; p.z += step * ((1.0 - u * u) * ru);
+        }
+        Quat qy; quat_unit(Quat{ 0.0, u, 0.0, 1.0 }, qy);
+        const Vec3 ps{ p.x / scale + 0.02 * nrm(seed, j, (uint64_t)i, 1), p.y / scale + 0.02 * nrm(seed, j, (uint64_t)i, 2),
+                       p.z / scale + 0.02 * nrm(seed, j, (uint64_t)i, 3) };
+        ts[ix.at(b, i, 0, 1)] = t;
+        pos[ix.at(b, i, 0, 3)] = ps.x; pos[ix.at(b, i, 1, 3)] = ps.y; pos[ix.at(b, i, 2, 3)] = ps.z;
+        quat[ix.at(b, i, 0, 4)] = qy.x; quat[ix.at(b, i, 1, 4)] = qy.y; quat[ix.at(b, i, 2, 4)] = qy.z; quat[ix.at(b, i, 3, 4)] = qy.w;
+        // fix i-1 sits between poses i-1 and i (camera axes: x right, y down, z forward -> east/north by the course, up = -y)
+        if (i > 0 && !(i - 1 >= o0 && i - 1 < o1)) {
+            const double f = phase / (t - t_prev);
+            const Vec3 g{ p_prev.x + f * (p.x - p_prev.x), p_prev.y + f * (p.y - p_prev.y), p_prev.z + f * (p.z - p_prev.z) };
+            const double east = ch * g.x + sh * g.z + 0.45 * nrm(seed, j, (uint64_t)i, 4), north = -sh * g.x + ch * g.z + 0.45 * nrm(seed, j, (uint64_t)i, 5);
+            gps_t[w] = t_prev + phase;
+            gps_llh[w * 3] = 49.0336 + north * SYN_DEG_PER_M_NORTH; gps_llh[w * 3 + 1] = 8.3950 + east * SYN_DEG_PER_M_EAST;
+            gps_llh[w * 3 + 2] = 112.0 - g.y + 0.45 * nrm(seed, j, (uint64_t)i, 6);
+            ++w;
+        }
+        t_prev = t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -152,6 +219,24 @@ int gsf_transpose_to_time_major_dev(gsf_ctx* ctx, const void* src, void* dst, in
 int gsf_transpose_to_traj_major_dev(gsf_ctx* ctx, const void* src, void* dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes)
 {
     return launch_transpose<false>(ctx, src, dst, B, N, C, elem_bytes);
+}
+
+int gsf_synth_geodetic_batch_dev(gsf_ctx* ctx, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double* ts, double* pos, double* quat,
+                                 int64_t* counts, const int64_t* gps_offsets, double* gps_t, double* gps_llh)
+{
+    GSF_REQUIRE(ctx && B >= 0 && N >= 0 && traj0 >= 0, "bad shape");
+    GSF_REQUIRE((counts != nullptr) != (gps_offsets != nullptr), "pass counts (sizing pass) OR gps_offsets (writing pass)");
+    if (B == 0 || N == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64), grid((unsigned)((B + 63) / 64));
+    if (counts) {
+        hipLaunchKernelGGL(synth_geodetic_kernel<false>, grid, block, 0, ctx->stream, seed, traj0, B, N, ts, pos, quat, counts, gps_offsets, gps_t, gps_llh);
+    } else {
+        GSF_REQUIRE(ts && pos && quat && gps_t && gps_llh, "NULL argument");
+        hipLaunchKernelGGL(synth_geodetic_kernel<true>, grid, block, 0, ctx->stream, seed, traj0, B, N, ts, pos, quat, counts, gps_offsets, gps_t, gps_llh);
+    }
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
 }
 
 int gsf_synth_batch_dev(gsf_ctx* ctx, int32_t layout, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double* ts, double* pos,

@@ -64,6 +64,45 @@ __global__ __launch_bounds__(256) void utm_kernel(const double* __restrict__ a, 
     }
 }
 
+// The geodesy slice of load_gps_data (ref :258-271) for B ragged GNSS logs in ONE launch, block per log: rows (lat, lon, alt) ->
+// validity mask (:259-264; rows the reference DROPS come back as NaN rows -- a fixed-shape device array cannot shrink), zone and
+// hemisphere from the means over the valid rows (:131-133), UTM forward, rows [E, N, alt] (:271).
+__global__ __launch_bounds__(256) void gps_rows_to_utm_kernel(const double* __restrict__ llh, const int64_t* __restrict__ offsets,
+                                                              double* __restrict__ enu, int32_t* __restrict__ zone, int32_t* __restrict__ south)
+{
+    __shared__ double sh[3][4];
+    __shared__ double sh_lon0, sh_fn;
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    double sl = 0.0, sp = 0.0, cnt = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const double la = llh[i * 3], lo = llh[i * 3 + 1];
+        const bool ok = (fabs(la) <= 90.0) && (fabs(lo) <= 180.0) && (la != 0.0) && (lo != 0.0);
+        if (ok) { sl += lo; sp += la; cnt += 1.0; }
+    }
+    sl = wave_sum(sl); sp = wave_sum(sp); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sl; sh[1][threadIdx.x >> 6] = sp; sh[2][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+        const double ml = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / n, mp = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / n;
+        const int32_t z = (n > 0.0) ? (int32_t)(floor((ml + 180.0) / 6.0) + 1.0) : 0;
+        const int32_t so = (n > 0.0 && mp < 0.0) ? 1 : 0;
+        zone[b] = z; south[b] = so;
+        sh_lon0 = 6.0 * (double)z - 183.0; sh_fn = so ? 10000000.0 : 0.0;
+    }
+    __syncthreads();
+    const double lon0 = sh_lon0, fn = sh_fn;
+    const TmConsts c = tm_consts();
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const double la = llh[i * 3], lo = llh[i * 3 + 1], al = llh[i * 3 + 2];
+        const bool ok = (fabs(la) <= 90.0) && (fabs(lo) <= 180.0) && (la != 0.0) && (lo != 0.0);
+        double e, n;
+        utm_forward_point(c, la, lo, lon0, fn, e, n);
+        enu[i * 3] = ok ? e : NAN; enu[i * 3 + 1] = ok ? n : NAN; enu[i * 3 + 2] = ok ? al : NAN;
+    }
+}
+
 // geodetic -> ENU about a per-trajectory origin (ref_llh[b] = lat0, lon0, h0), lane per point
 __global__ __launch_bounds__(256) void enu_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ alt,
                                                   const int64_t* __restrict__ offsets, const double* __restrict__ ref_llh,
@@ -117,6 +156,18 @@ int gsf_utm_inverse_batch_dev(gsf_ctx* ctx, const double* easting, const double*
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(utm_kernel<true>, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, easting, northing, offsets, zone, south, lat, lon);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_gps_rows_to_utm_batch_dev(gsf_ctx* ctx, const double* llh, const int64_t* offsets, int64_t B, double* utm_rows, int32_t* zone, int32_t* south)
+{
+    GSF_REQUIRE(ctx && offsets && zone && south, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(llh && utm_rows, "NULL rows");
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gps_rows_to_utm_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, llh, offsets, utm_rows, zone, south);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

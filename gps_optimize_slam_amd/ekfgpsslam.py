@@ -284,9 +284,10 @@ def compute_sim3_transform(src, dst):
 
 
 def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max_trials, min_inliers_needed, point_description="pts"):
-    """RANSAC-wrapped Sim3 (ref :389-426).  The sample indices are drawn here with the reference's own RNG call
-    (np.random.choice(n, min_samples, replace=False) per trial, legacy global stream, ref :405); hypothesis
-    fitting, scoring, arg-max and the final inlier fit run in one K2b launch."""
+    """RANSAC-wrapped Sim3 (ref :389-426) in ONE library call: the hypotheses' rows are drawn on the device from NumPy's global
+    legacy generator state -- the same np.random.choice(n, min_samples, replace=False) per trial as ref :405, bit for bit -- then
+    fitted, scored, arg-maxed and refitted on the inliers; the advanced state is handed back to np.random, so a seeded run keeps
+    drawing what the reference would draw next."""
     src, dst = np.asarray(src, dtype=np.float64), np.asarray(dst, dtype=np.float64)
     n_points = src.shape[0]
     if n_points < min_samples:
@@ -295,11 +296,24 @@ def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max
         return None, None, None
     if not 1 <= int(min_samples) <= 8:
         raise ValueError("min_samples must be in [1, 8] for the device RANSAC")
-    idx = np.empty((int(max_trials), int(min_samples)), dtype=np.int32)
-    for k in range(int(max_trials)):
-        idx[k] = np.random.choice(n_points, min_samples, replace=False)
-    res = sim3_ransac_with_indices(src, dst, idx, residual_threshold, min_inliers_needed)
-    return res[:3]
+    if n_points > 28000:                                                 # beyond the device sampler's LDS budget: host draws (ref :405)
+        idx = np.empty((int(max_trials), int(min_samples)), dtype=np.int32)
+        for k in range(int(max_trials)):
+            idx[k] = np.random.choice(n_points, min_samples, replace=False)
+        return sim3_ransac_with_indices(src, dst, idx, residual_threshold, min_inliers_needed)[:3]
+    src, dst = np.ascontiguousarray(src), np.ascontiguousarray(dst)
+    kind, key, pos, has_gauss, cached = np.random.get_state()
+    state = np.concatenate([key.astype(np.uint32), np.array([pos], dtype=np.uint32)])
+    off = np.array([0, n_points], dtype=np.int64)
+    R, t, s = np.empty((1, 9)), np.empty((1, 3)), np.empty(1)
+    st, nin, mask = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(n_points, dtype=np.uint8)
+    check(_lib.load().gsf_sim3_ransac_mt_batch(_ctx().handle, hptr(src), hptr(dst), hptr(off), 1, hptr(state), int(max_trials), int(min_samples),
+                                               float(residual_threshold), int(min_inliers_needed), hptr(R), hptr(t), hptr(s), hptr(st), hptr(mask),
+                                               hptr(nin)))
+    np.random.set_state((kind, state[:624], int(state[624]), has_gauss, cached))
+    if st[0] & _lib.SIM3_NONE:
+        return None, None, None
+    return R.reshape(3, 3), t.reshape(3), float(s[0])
 
 
 def sim3_ransac_with_indices(src, dst, sample_idx, residual_threshold, min_inliers_needed):
@@ -494,6 +508,55 @@ def pick_sim3_indices(slam_data, valid_mask, config=None):
     lim = slam_data["timestamps"][first] <= slam_data["timestamps"][first[0]] + config["sim3_ransac"]["max_initial_duration"]
     timed = first[lim]
     return first if len(timed) < ms else timed
+
+
+def benchmark_c1(repeats=20, golden_dir=None):
+    """Warm wall time of the single-trajectory drop-in at the C1 shape (BASELINE configs[0]: the 271-pose KITTI-04 track and its
+    279 raw GNSS fixes, taken from the committed fixtures tests/golden/{kat_bundled,c1_combined}.npz -- data only): the GPS leg of
+    step 1 (projection + sliding RANSAC pre-filter, ref :266-275), steps 2-5 (time alignment, robust Sim3, apply, EKF+RTS,
+    ref :971-1010) and step 6 (error metric).  BASELINE.md's CPU figures for the reference: ~0.11 s for steps 2-5, 23-40 ms for
+    the pre-filter."""
+    import os
+    import time
+    if golden_dir is None:
+        golden_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    k, g = np.load(os.path.join(golden_dir, "kat_bundled.npz")), np.load(os.path.join(golden_dir, "c1_combined.npz"))
+    slam = {"timestamps": k["ts"].copy(), "positions": k["pos"].copy(), "quaternions": k["quat"].copy()}
+    ts, lats, lons, alts = g["gps_t_raw"].copy(), g["lat"].copy(), g["lon"].copy(), g["alt"].copy()
+    config = copy.deepcopy(CONFIG)
+    sc = config["sim3_ransac"]
+
+    def gps_leg():
+        zone, hemi = auto_utm_projection(lons, lats)
+        projector = UtmProjector(zone, "south" in hemi)
+        x, y = projector(lons, lats)
+        ft, fp = filter_gps_outliers_ransac(ts, np.column_stack((x, y, alts)), config["gps_filtering_ransac"])
+        return {"timestamps": ft, "positions": fp, "projector": projector}
+
+    def steps_2_to_5(gps):
+        aligned, valid = dynamic_time_alignment(slam, gps, config["time_alignment"])
+        idx = pick_sim3_indices(slam, valid, config)
+        R, t, s = compute_sim3_transform_robust(slam["positions"][idx], aligned[idx], sc["min_samples"], sc["residual_threshold"], sc["max_trials"],
+                                                sc["min_inliers_needed"])
+        sp, sq = transform_trajectory(slam["positions"], slam["quaternions"], R, t, s)
+        pos, quat = apply_ekf_correction(slam, gps, sp, sq, config)
+        return aligned, valid, pos
+
+    out = {}
+    np.random.seed(0)
+    gps = gps_leg(); aligned, valid, pos = steps_2_to_5(gps)             # warm-up (first calls allocate the staging arenas)
+    for name, fn in (("gps_projection_and_prefilter_ms", gps_leg), ("steps_2_to_5_ms", lambda: steps_2_to_5(gps)),
+                     ("step_6_error_metric_ms", lambda: evaluate_trajectory_errors(slam["timestamps"], pos, aligned, valid))):
+        best, tot = 1e9, 0.0
+        for _ in range(repeats):
+            t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+            best, tot = min(best, dt), tot + dt
+        out[name] = {"best": best * 1e3, "mean": tot / repeats * 1e3}
+    out["end_to_end_ms"] = {"best": sum(v["best"] for v in out.values()), "mean": sum(v["mean"] for v in out.values())}
+    out["poses"] = int(len(slam["timestamps"]))
+    out["gnss_fixes"] = int(len(ts))
+    out["reference_cpu_ms"] = {"steps_2_to_5": 110.0, "prefilter": "23-40", "source": "BASELINE.md (survey probe, 1 core)"}
+    return out
 
 
 def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):

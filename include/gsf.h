@@ -120,6 +120,13 @@ GSF_API int gsf_utm_forward(gsf_ctx *ctx, const double *lat_deg, const double *l
 GSF_API int gsf_utm_inverse(gsf_ctx *ctx, const double *easting, const double *northing, int64_t n, int32_t zone, int32_t south,
                     double *lat_deg, double *lon_deg);
 
+/* The whole geodesy slice of load_gps_data (EKFGPSSLAM.py:258-271) for B ragged GNSS logs in one launch: rows llh[total][3] =
+   (lat deg, lon deg, alt m) -- columns 1,2,3 of the reference's text file -- are masked (:259-264), each log's zone / hemisphere
+   is picked from the means over its valid rows (:131-133), and rows utm_rows[total][3] = (E, N, alt) come back (:271).  Rows the
+   reference drops are NaN rows here (a device array cannot shrink); zone[b] = 0 for a log without a valid row. */
+GSF_API int gsf_gps_rows_to_utm_batch_dev(gsf_ctx *ctx, const double *llh, const int64_t *offsets, int64_t B, double *utm_rows, int32_t *zone,
+                                          int32_t *south);
+
 /* WGS84 geodetic -> local East-North-Up about a per-trajectory origin ref_llh[B][3] = (lat0 deg, lon0 deg, h0 m).  Offered in
    addition to UTM: the reference's pipeline projects with UTM (EKFGPSSLAM.py:266-271); BASELINE.json words the step as
    "WGS84 -> local ENU". */
@@ -159,6 +166,13 @@ GSF_API int gsf_sim3_ransac_batch(gsf_ctx *ctx, const double *src, const double 
                           const int32_t *sample_idx, int32_t trials, int32_t min_samples, double residual_threshold,
                           int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,
                           uint8_t *inlier_mask, int32_t *n_inliers);
+
+/* The same with the draws made ON THE DEVICE from NumPy's legacy generator state (host pointers; mt_state[B][625] uint32 in/out =
+   np.random.get_state()[1:3] per set, see gsf_mt19937_*): one call instead of `trials` host-side np.random.choice calls, and the
+   caller's generator ends where the reference leaves it. */
+GSF_API int gsf_sim3_ransac_mt_batch(gsf_ctx *ctx, const double *src, const double *dst, const int64_t *offsets, int64_t B, uint32_t *mt_state,
+                                     int32_t trials, int32_t min_samples, double residual_threshold, int32_t min_inliers_needed, double *R,
+                                     double *t, double *s, int32_t *status, uint8_t *inlier_mask, int32_t *n_inliers);
 
 /* ---- the reference's random draws on the device (np.random.choice(n, k, replace=False), EKFGPSSLAM.py:405) ---------- */
 /* state: uint32[B][625] = NumPy's legacy MT19937 state per stream, key[624] then pos -- exactly np.random.get_state()[1:3], so a
@@ -287,8 +301,13 @@ GSF_API int gsf_allgather_poses(gsf_ctx *ctx, void *nccl_comm, const double *sen
 GSF_API int gsf_transpose_to_time_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);
 GSF_API int gsf_transpose_to_traj_major_dev(gsf_ctx *ctx, const void *src, void *dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes);
 /* deterministic KITTI-04-shaped synthetic batch, generated on device straight into `layout`;
-   trajectory ids [traj0, traj0+B).  Integer counter-based RNG + polynomial curves only: the host generator in
-   gps_optimize_slam_amd/synth.py produces bit-identical values. */
+   trajectory ids [traj0, traj0+B).  Integer counter-based RNG + polynomial / rational curves only (no libm call), so the values do
+   not depend on a math library and a shard generated with traj0 = k equals rows k.. of the full batch bit for bit. */
+/* the same trajectories with the GNSS side as a ragged GEODETIC log (fixes at their own stamps, rows (lat, lon, alt) about
+   49.0336 N 8.3950 E, outages = missing fixes): the input of the device chain K1 -> time alignment -> fit -> EKF.  Two passes:
+   counts != NULL sizes (counts[B] int64 fixes per trajectory), gps_offsets != NULL writes rows at gps_offsets[b]. */
+GSF_API int gsf_synth_geodetic_batch_dev(gsf_ctx *ctx, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double *ts, double *pos,
+                                         double *quat, int64_t *counts, const int64_t *gps_offsets, double *gps_t, double *gps_llh);
 GSF_API int gsf_synth_batch_dev(gsf_ctx *ctx, int32_t layout, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double *ts,
                         double *pos, double *quat, double *gps, uint8_t *valid, double *init_pos, double *init_quat);
 

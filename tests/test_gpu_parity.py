@@ -843,6 +843,45 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
+def test_device_chain_from_geodetic_log_vs_oracle(B, orc):
+    """K1 (mask, zone pick, UTM forward) -> time alignment -> fit -> EKF+RTS from a ragged geodetic GNSS log without leaving the
+    device, against the oracle chained the same way (load_gps_data's geodesy slice :258-271, dynamic_time_alignment :325-387,
+    steps 3-5 :1002-1010)."""
+    nb, N = 96, 271
+    gb = B.GeodeticBatch.synthetic(nb, N, seed=5)
+    out, R, t, s, aux = B.fuse_from_geodetic(gb)
+    p, q, st = out.host_traj_major()
+    offs = gb.gps_offsets.cpu().numpy()
+    gt, llh = gb.gps_t.cpu().numpy(), gb.gps_llh.cpu().numpy()
+    ts, pos, quat = gb.ts.cpu().numpy(), gb.pos.cpu().numpy(), gb.quat.cpu().numpy()
+    utm, aligned, valid = aux["utm_rows"].cpu().numpy(), aux["aligned"].cpu().numpy(), aux["valid"].cpu().numpy()
+    zone, south = aux["zone"].cpu().numpy(), aux["south"].cpu().numpy()
+    assert (zone == 32).all() and (south == 0).all()                    # 8.395 E, 49.03 N (SURVEY 8c: lon 8.39 -> zone 32)
+    n_gap = 0
+    for b in range(nb):
+        lo, hi = offs[b], offs[b + 1]
+        zo, hemi = orc.auto_utm_projection(llh[lo:hi, 1], llh[lo:hi, 0])
+        assert zo == zone[b] and ("south" in hemi) == bool(south[b])
+        e, n = orc.utm_forward(llh[lo:hi, 0], llh[lo:hi, 1], zo, "south" in hemi)
+        rows = np.column_stack((e, n, llh[lo:hi, 2]))
+        np.testing.assert_allclose(utm[lo:hi], rows, atol=5e-9, rtol=0)
+        al, va = orc.dynamic_time_alignment(ts[b], gt[lo:hi], rows, 500, 5.0)
+        np.testing.assert_array_equal(valid[b].astype(bool), va)
+        np.testing.assert_allclose(aligned[b][va], al[va], atol=1e-8, rtol=0)
+        n_gap += int(not va[1:-1].all())
+    assert n_gap >= 5                                                   # outages (missing fixes, gap > 5 s) really occur
+    po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(ts, pos, quat, aligned, valid)
+    ok = np.isfinite(po).all(axis=(1, 2))
+    assert ok.sum() >= nb - 2
+    assert np.abs(p[ok] - po[ok]).max() < POS_TOL and np.abs(q[ok] - qo[ok]).max() < 1e-8
+    np.testing.assert_array_equal(st[ok] & 0xff, sto[ok] & 0xff)
+    # shards of the generator: ids [k, k+32) generated separately == rows of the full batch
+    part = B.GeodeticBatch.synthetic(32, N, seed=5, traj0=32)
+    o32 = offs[32]
+    np.testing.assert_array_equal(part.ts.cpu().numpy(), ts[32:64])
+    np.testing.assert_array_equal(part.gps_llh.cpu().numpy(), llh[o32:offs[64]])
+
+
 def test_device_mt19937_choice_matches_numpy(B):
     """np.random.choice(n, k, replace=False) of NumPy's legacy generator reproduced on the device: the same sample sets trial by
     trial AND the same generator state afterwards (the next NumPy draw continues the stream), for seeded streams and for a state
