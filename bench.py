@@ -439,9 +439,14 @@ def worker(args):
     poses_per_step = world * Bn * N
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    duo = args.kernel == "pipeline" and Bn <= 768 and 64 < N <= 640
-    kernel_name = "ekf_wave_duo_kernel<true>" if duo else "ekf_wave_kernel<%s, %s>" % ("true" if args.kernel == "pipeline" else "false", "true" if Bn <= 2048 else "false")
-    grid_threads = Bn * (128 if duo else 64)
+    # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; all three produce identical bits)
+    pipe = args.kernel == "pipeline"
+    if pipe and 64 < N <= 384 and 512 < Bn <= 1024:
+        kernel_name, grid_threads = "ekf_wave_quad_kernel<true>", ((Bn + 3) // 4) * 512       # four trajectories per 512-thread block, helper waves
+    elif pipe and 64 < N <= 640 and Bn <= 512:
+        kernel_name, grid_threads = "ekf_wave_duo_kernel<true>", Bn * 128
+    else:
+        kernel_name, grid_threads = "ekf_wave_kernel<%s, %s>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
     traffic, traffic_src = profiled_traffic(args.workload, kernel_name, grid_threads)
     result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
                   config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)",

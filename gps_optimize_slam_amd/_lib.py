@@ -74,6 +74,8 @@ SIGNATURES = {
     "gsf_gps_rows_to_utm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_geodetic_to_enu_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_ransac_poly_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
+    "gsf_gps_prefilter_chain_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "gsf_gps_prefilter_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

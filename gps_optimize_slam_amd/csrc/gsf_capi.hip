@@ -306,10 +306,12 @@ int gsf_sim3_ransac_mt_batch(gsf_ctx* ctx, const double* src, const double* dst,
     const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (src && dst)), "bad offsets / NULL points");
     std::vector<int32_t> counts((size_t)B);
+    int32_t n_max = 1;
     for (int64_t b = 0; b < B; ++b) {
         const int64_t n = offsets[b + 1] - offsets[b];
         GSF_REQUIRE(n >= 0 && n <= 28000, "a point set has more than 28000 rows (device-side draws) or negative length");
         counts[(size_t)b] = (int32_t)n;
+        if ((int32_t)n > n_max) n_max = (int32_t)n;
     }
     const size_t nidx = (size_t)B * (size_t)trials * (size_t)min_samples;
     ST_BEGIN((size_t)total * 49 + (size_t)(B + 1) * 8 + (size_t)B * (625 * 8 + 4 + 112) + nidx * 4, 14);
@@ -325,7 +327,7 @@ int gsf_sim3_ransac_mt_batch(gsf_ctx* ctx, const double* src, const double* dst,
     int rc = st.upload();
     if (rc) return rc;
     GSF_HIP(hipMemcpyAsync(dstate, dst_in, (size_t)B * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    if (trials > 0 && (rc = launch_mt_choice(ctx, dstate, dcnt, B, trials, min_samples, didx))) return rc;
+    if (trials > 0 && (rc = launch_mt_choice(ctx, dstate, dcnt, B, trials, min_samples, didx, n_max))) return rc;
     if ((rc = launch_sim3_ransac(ctx, dsrc, ddst, doff, nullptr, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni))) return rc;
     return st.finish();
 }

@@ -13,7 +13,7 @@
 //      would have drawn, which the host needs to put the RNG where the reference leaves it;
 //   3. writes the inlier mask of the accepted model.
 // One 128-thread block per problem; rows of a problem are contiguous ([total] arrays + int64 offsets[P+1]).
-#include "gsf_internal.hpp"
+#include "gsf_mt19937.hpp"
 
 using namespace gsf;
 
@@ -36,14 +36,14 @@ __device__ __forceinline__ double poly_predict(const PolyModel& m, int degree, d
 // the least squares by modified Gram-Schmidt (the constant column is identically zero after centring: coefficient 0),
 // intercept = mean(y) - sum coef_k mean(t^k).
 __device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
-                                                int ms, int degree)
+                                                int ms, int degree, int ystride = 1)
 {
     double c[RP_MAX_DEGREE][RP_MAX_SAMPLES], yy[RP_MAX_SAMPLES], mean[RP_MAX_DEGREE] = { 0, 0, 0 }, ymean = 0.0;
     for (int i = 0; i < ms; ++i) {
         const double ti = t[idx[i]];
         double tk = ti;
         for (int k = 0; k < degree; ++k) { c[k][i] = tk; mean[k] += tk; tk *= ti; }
-        yy[i] = y[idx[i]]; ymean += yy[i];
+        yy[i] = y[(int64_t)idx[i] * ystride]; ymean += yy[i];
     }
     const double rn = 1.0 / (double)ms;
     ymean *= rn;
@@ -157,6 +157,127 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
     for (int i = tau; i < n; i += RP_THREADS) inlier_mask[i0 + i] = fabs(yp[i] - poly_predict(mb, degree, tp[i])) <= thr ? 1 : 0;
 }
 
+// score of one fed trial (steps 1 of the header comment) for rows with a stride (AoS position rows)
+__device__ __forceinline__ void score_trial(const double* __restrict__ tp, const double* __restrict__ yp, int ystride, int n, const int32_t* idx, int ms,
+                                            int degree, double thr, int& cnt_out, double& score_out)
+{
+    const PolyModel m = fit_subset(tp, yp, idx, ms, degree, ystride);
+    int cnt = 0; double sy = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+        const double yi = yp[(int64_t)i * ystride];
+        const double res = fabs(yi - poly_predict(m, degree, tp[i]));
+        if (res <= thr) { ++cnt; sy += yi; }
+    }
+    double score = NAN;
+    if (cnt >= 2) {
+        const double ym = sy / (double)cnt;
+        double ss_res = 0.0, ss_tot = 0.0;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            const double yi = yp[(int64_t)i * ystride];
+            const double pr = poly_predict(m, degree, tp[i]);
+            if (fabs(yi - pr) <= thr) { ss_res += (yi - pr) * (yi - pr); ss_tot += (yi - ym) * (yi - ym); }
+        }
+        score = ss_tot != 0.0 ? 1.0 - ss_res / ss_tot : (ss_res == 0.0 ? 1.0 : 0.0);
+    }
+    cnt_out = cnt; score_out = score;
+}
+
+// The WHOLE pre-filter of one GNSS log as one device chain (ref :183-247 sliding windows, :148-182 the single global window): for
+// every window (row range, found by the host from the stamps) and every coordinate axis in the reference's order -- draw max_trials
+// sample sets from the log's legacy MT19937 stream exactly like scikit-learn's sample_without_replacement (permutation(n)[:k] for
+// 0.01 < k/n < 0.99), score them, walk scikit-learn's acceptance rule, REWIND the stream to where n_trials_ draws leave it, and
+// either AND the axis mask into the window mask or -- no consensus set: the reference's exception -- drop the window and skip its
+// remaining axes (they consume nothing).  keep[] = OR over the successful windows.  One wave per log.
+constexpr int CH_MAX_TRIALS = 1024;
+__global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* __restrict__ t, const double* __restrict__ pos, const int64_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ win_rows, const int64_t* __restrict__ win_offsets,
+                                                                 int max_trials, int ms, int degree, double thr, double stop_prob, int jseq_elems,
+                                                                 uint32_t* __restrict__ state, uint8_t* __restrict__ keep, int32_t* __restrict__ win_status,
+                                                                 int32_t* __restrict__ log_status)
+{
+    __shared__ uint32_t mt[MT_N + 1];
+    __shared__ uint32_t snap[MT_N + 1];
+    __shared__ int sh_nin[CH_MAX_TRIALS];
+    __shared__ double sh_score[CH_MAX_TRIALS];
+    __shared__ int32_t sh_end[CH_MAX_TRIALS];
+    __shared__ int sh_res[3];
+    extern __shared__ uint16_t dyn[];                                     // [jseq_elems] swap partners, then int32 idx[max_trials * ms]
+    uint16_t* jseq = dyn;
+    int32_t* sh_idx = (int32_t*)(dyn + ((jseq_elems + 1) & ~1));
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t r_base = offsets[b];
+    const int n_log = (int)(offsets[b + 1] - r_base);
+    uint32_t* st = state + b * MT_STATE_WORDS;
+    for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
+    int pos_mt = (int)st[MT_N];
+    for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 0;
+    __syncthreads();
+    int lstat = 0;
+    for (int64_t w = win_offsets[b]; w < win_offsets[b + 1]; ++w) {
+        const int r0 = win_rows[w * 2], r1 = win_rows[w * 2 + 1], n = r1 - r0;
+        int wstat = 0;
+        if (n < ms || r0 < 0 || r1 > n_log) { if (lane == 0) win_status[w] = 2; continue; }           // ref :209: too few rows, window not processed
+        // scikit-learn's sampler takes the permutation route only for 0.01 < k/n < 0.99; other ratios (tracking selection / reservoir
+        // sampling) are not restated on the device: the log is flagged and left to the host-drawn path
+        const double ratio = (double)ms / (double)n;
+        if (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems) { lstat = 2; if (lane == 0) win_status[w] = 3; break; }
+        const double* tp = t + r_base + r0;
+        // window mask lives in keep[] itself as bit 1 (AND over axes), folded into bit 0 (OR over windows) when the window succeeds
+        for (int i = lane; i < n; i += 64) keep[r_base + r0 + i] |= 2;
+        for (int ax = 0; ax < 3 && wstat == 0; ++ax) {
+            const double* yp = pos + (r_base + r0) * 3 + ax;
+            for (int i = lane; i <= MT_N; i += 64) snap[i] = (i < MT_N) ? mt[i] : (uint32_t)pos_mt;
+            __syncthreads();
+            mt_draw_choice(mt, pos_mt, n, max_trials, ms, jseq, jseq_elems, sh_idx, sh_end, lane);
+            for (int tau = lane; tau < max_trials; tau += 64) {
+                int c; double sc;
+                score_trial(tp, yp, 3, n, sh_idx + (size_t)tau * ms, ms, degree, thr, c, sc);
+                sh_nin[tau] = c; sh_score[tau] = sc;
+            }
+            __syncthreads();
+            if (lane == 0) {                                              // RANSACRegressor.fit's loop over the trials, in order
+                int best = -1, best_n = 1, ntr = 0;
+                double best_score = -INFINITY, max_tr = (double)max_trials;
+                while ((double)ntr < max_tr) {
+                    const int k = ntr++;
+                    const int c = sh_nin[k];
+                    if (c < best_n) continue;
+                    const double sc = sh_score[k];
+                    if (c == best_n && sc < best_score) continue;
+                    best = k; best_n = c; best_score = sc;
+                    max_tr = fmin(max_tr, dynamic_max_trials(best_n, n, ms, stop_prob));
+                }
+                sh_res[0] = best; sh_res[1] = ntr; sh_res[2] = ntr > 0 ? sh_end[ntr - 1] : 0;
+            }
+            __syncthreads();
+            const int best = sh_res[0], skip = sh_res[2];
+            // the stream goes back to the window-axis start and forward by what n_trials_ draws consume
+            for (int i = lane; i < MT_N; i += 64) mt[i] = snap[i];
+            pos_mt = (int)snap[MT_N];
+            __syncthreads();
+            mt_skip(mt, pos_mt, skip, lane);
+            if (best < 0) { wstat = 1; break; }                           // "RANSAC could not find a valid consensus set": the window fails (ref :228-229)
+            const PolyModel mb = fit_subset(tp, yp, sh_idx + (size_t)best * ms, ms, degree, 3);
+            for (int i = lane; i < n; i += 64) {
+                const bool in = fabs(yp[(int64_t)i * 3] - poly_predict(mb, degree, tp[i])) <= thr;
+                if (!in) keep[r_base + r0 + i] &= (uint8_t)~2u;
+            }
+            __syncthreads();
+        }
+        for (int i = lane; i < n; i += 64) {
+            const uint8_t v = keep[r_base + r0 + i];
+            keep[r_base + r0 + i] = (uint8_t)((v & 1u) | ((wstat == 0 && (v & 2u)) ? 1u : 0u));
+        }
+        if (lane == 0) win_status[w] = wstat;
+        __syncthreads();
+    }
+    for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
+    if (lane == 0) { st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,6 +298,58 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
                        (int)min_samples, (int)degree, residual_threshold, stop_probability, inlier_mask, n_trials, n_inliers, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
+}
+
+int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, int64_t B, const int32_t* win_rows,
+                                const int64_t* win_offsets, int32_t max_window_rows, int32_t max_trials, int32_t min_samples, int32_t degree,
+                                double residual_threshold, double stop_probability, uint32_t* mt_state, uint8_t* keep, int32_t* win_status,
+                                int32_t* log_status)
+{
+    GSF_REQUIRE(ctx && offsets && win_rows && win_offsets && mt_state && keep && win_status && log_status, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    GSF_REQUIRE(max_trials >= 1 && max_trials <= CH_MAX_TRIALS, "max_trials must be in [1,1024]");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= RP_MAX_SAMPLES, "min_samples must be in [1,16]");
+    GSF_REQUIRE(degree >= 1 && degree <= RP_MAX_DEGREE, "polynomial degree must be in [1,3]");
+    GSF_REQUIRE(max_window_rows >= 1 && max_window_rows <= 14000, "max_window_rows must be in [1,14000]");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(t && pos, "NULL rows");
+    GSF_HIP(hipSetDevice(ctx->device));
+    // dynamic LDS (40 KB next to 21 KB of static arrays): the sample sets of one window-axis, then the swap partners of as many trials
+    // as the rest allows (at least one trial's worth)
+    const size_t idx_bytes = (size_t)max_trials * (size_t)min_samples * 4;
+    GSF_REQUIRE(idx_bytes + 2 * (size_t)max_window_rows + 4 <= 40 * 1024, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
+    int tb = (int)((40 * 1024 - idx_bytes - 4) / 2 / (size_t)max_window_rows); if (tb > 64) tb = 64;
+    const int jseq_elems = tb * max_window_rows;
+    const size_t lds = (size_t)((jseq_elems + 1) & ~1) * 2 + idx_bytes;
+    hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, win_rows, win_offsets, (int)max_trials,
+                       (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_gps_prefilter_chain(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, int64_t B, const int32_t* win_rows,
+                            const int64_t* win_offsets, int32_t max_window_rows, int32_t max_trials, int32_t min_samples, int32_t degree,
+                            double residual_threshold, double stop_probability, uint32_t* mt_state, uint8_t* keep, int32_t* win_status, int32_t* log_status)
+{
+    GSF_REQUIRE(ctx && offsets && win_offsets && mt_state && keep && log_status && B >= 0, "bad arguments");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B], nw = win_offsets[B];
+    GSF_REQUIRE(total >= 0 && nw >= 0 && (total == 0 || (t && pos)) && (nw == 0 || (win_rows && win_status)), "bad offsets / NULL arrays");
+    Staging st(ctx, (size_t)total * 33 + (size_t)(B + 1) * 16 + (size_t)nw * 12 + (size_t)B * (625 * 8 + 4), 12);
+    if (st.rc()) return st.rc();
+    const double* dt = st.in(t, (size_t)total); const double* dp = st.in(pos, (size_t)total * 3);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1); const int32_t* dwr = st.in(win_rows, (size_t)nw * 2);
+    const int64_t* dwo = st.in(win_offsets, (size_t)B + 1);
+    const uint32_t* dst_in = st.in(mt_state, (size_t)B * 625);
+    uint32_t* dstate = st.out(mt_state, (size_t)B * 625);
+    uint8_t* dkeep = st.out(keep, (size_t)total); int32_t* dws = st.out(win_status, (size_t)nw); int32_t* dls = st.out(log_status, (size_t)B);
+    int rc = st.upload();
+    if (rc) return rc;
+    GSF_HIP(hipMemcpyAsync(dstate, dst_in, (size_t)B * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = gsf_gps_prefilter_chain_dev(ctx, dt, dp, doff, B, dwr, dwo, max_window_rows, max_trials, min_samples, degree, residual_threshold, stop_probability,
+                                     dstate, dkeep, dws, dls);
+    if (rc) return rc;
+    return st.finish();
 }
 
 }  // extern "C"

@@ -66,7 +66,8 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
                        double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers);
 // sample sets of the reference's RNG call, generated on the device (gsf_rng.hip): permutation(n_b)[:k] per trial from each set's
 // legacy MT19937 state; n_b = counts[b] (int32) -- asynchronous on the context's stream
-int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx);
+int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx,
+                     int32_t n_max /* largest counts[b] if the host knows it, else 0 */);
 
 // Staging of the host-pointer entry points.  ONE grow-only device arena per context plus a pinned host mirror of it: the
 // inputs of a call are packed into the mirror and cross PCIe in one hipMemcpyAsync, the outputs come back in one, and no call

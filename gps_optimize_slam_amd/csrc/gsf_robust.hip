@@ -122,7 +122,7 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
     int32_t* fit = (int32_t*)(w + o_fit); int32_t* fail = (int32_t*)(w + o_fail); double* ip = (double*)(w + o_ip); double* iq = (double*)(w + o_iq);
     hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, B, N, src, dst, rowmap, counts, offsets);
     GSF_HIP(hipGetLastError());
-    if (max_trials > 0 && (rc = launch_mt_choice(ctx, mt_state, counts, B, max_trials, min_samples, idx))) return rc;
+    if (max_trials > 0 && (rc = launch_mt_choice(ctx, mt_state, counts, B, max_trials, min_samples, idx, (int32_t)N))) return rc;
     if ((rc = launch_sim3_ransac(ctx, src, dst, offsets, counts, B, idx, max_trials, min_samples, residual_threshold, min_inliers_needed, R, t, s, fit,
                                  mask_c, n_inliers))) return rc;
     hipLaunchKernelGGL(robust_init_pose_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, pos, quat, B, N, R, t, s, fit, ip, iq, fail);

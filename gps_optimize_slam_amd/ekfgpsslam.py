@@ -143,46 +143,21 @@ def _ransac_axes_mask(t, p, degree, min_samples, residual_threshold, max_trials)
     return keep
 
 
-def filter_gps_outliers_ransac(times, positions, config):
-    """The reference's optional GPS pre-filter (ref :136-247, SURVEY 8(f) next-3): per-axis degree-d polynomial RANSAC, AND
-    across axes; either one global fit or sliding windows [t, t+W) advanced by W*step_factor with one extra tail window, OR
-    across windows -- rows never inside a fitted window are dropped.  The RANSAC itself (the reference's scikit-learn
-    RANSACRegressor over PolynomialFeatures + LinearRegression) runs on the GPU (gsf_ransac_poly_batch_dev); only the sample sets
-    are drawn on the host, with scikit-learn's sampler on the global legacy RNG, so a seeded run keeps the same rows and leaves
-    the RNG in the same state as the reference."""
-    if not config.get("enabled", False):
-        return times, positions
-    n_points, need = len(times), config["min_samples"]
-    if n_points < need:
-        return times, positions
-    degree, thr, trials = config["polynomial_degree"], config["residual_threshold_meters"], config["max_trials"]
-
-    def axes_mask(t, p):
-        return _ransac_axes_mask(np.asarray(t, dtype=np.float64), np.asarray(p, dtype=np.float64), degree, need, thr, trials)
-
-    if not config.get("use_sliding_window", False):                      # ref :148-182
-        try:
-            keep = axes_mask(times, positions)
-            return times[keep], positions[keep]
-        except GsfError:
-            raise
-        except Exception:
-            return times, positions
-    width = config["window_duration_seconds"]                            # ref :183-247
+def _prefilter_windows(times, config, need):
+    """Row ranges [r0, r1) of the windows the reference visits, in its order (ref :199-234); the global mode is one window."""
+    n_points = len(times)
+    if not config.get("use_sliding_window", False):
+        return [(0, n_points)], None
+    width = config["window_duration_seconds"]
     stride = width * config["window_step_factor"]
-    keep = np.zeros(n_points, dtype=bool)
+    wins, rows_of = [], []
     t_first, t_last = times[0], times[-1]
     w0 = t_first
     while w0 < t_last:
         w1 = w0 + width
         rows = np.where((times >= w0) & (times < w1))[0]
         if len(rows) >= need:
-            try:
-                keep[rows[axes_mask(times[rows], positions[rows])]] = True
-            except GsfError:
-                raise
-            except Exception:
-                pass                                                     # a failed window marks nothing (ref :228-229)
+            wins.append(rows)
         if stride <= 1e-6:
             later = np.where(times > w0)[0]
             if len(later) == 0:
@@ -192,6 +167,67 @@ def filter_gps_outliers_ransac(times, positions, config):
             w0 += stride
         if w0 >= t_last and times[-1] >= w1:                             # one tail window ending just past the last stamp
             w0 = max(t_first, times[-1] - width + 1e-6)
+    contiguous = all(len(r) == r[-1] - r[0] + 1 for r in wins)          # sorted stamps: every window is one row range
+    return ([(int(r[0]), int(r[-1]) + 1) for r in wins] if contiguous else None), wins
+
+
+def filter_gps_outliers_ransac(times, positions, config):
+    """The reference's optional GPS pre-filter (ref :136-247, SURVEY 8(f) next-3): per-axis degree-d polynomial RANSAC, AND
+    across axes; either one global fit or sliding windows [t, t+W) advanced by W*step_factor with one extra tail window, OR
+    across windows -- rows never inside a fitted window are dropped.  The whole filter is ONE library call
+    (gsf_gps_prefilter_chain): every window and axis in the reference's order, the sample sets drawn on the device from NumPy's
+    global legacy generator exactly as scikit-learn's sampler draws them, the generator handed back where the reference leaves
+    it -- a seeded run keeps the same rows.  Logs the device sampler does not cover (unsorted stamps, min_samples/n outside
+    (0.01, 0.99)) take the window-by-window route with host-drawn sample sets (_ransac_axes_mask)."""
+    if not config.get("enabled", False):
+        return times, positions
+    n_points, need = len(times), config["min_samples"]
+    if n_points < need:
+        return times, positions
+    degree, thr, trials = config["polynomial_degree"], config["residual_threshold_meters"], config["max_trials"]
+    sliding = bool(config.get("use_sliding_window", False))
+    times, positions = np.asarray(times), np.asarray(positions)
+    ranges, wins = _prefilter_windows(times, config, need)
+    if ranges is not None and positions.shape[1] == 3 and max((b - a for a, b in ranges), default=0) <= 14000:
+        if not ranges:
+            return times[:0], positions[:0]                              # no window had enough rows: nothing is ever marked (ref :199-236)
+        kind, key, pos_, has_gauss, cached = np.random.get_state()
+        state = np.concatenate([key.astype(np.uint32), np.array([pos_], dtype=np.uint32)])
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        p = np.ascontiguousarray(positions, dtype=np.float64)
+        wr = np.ascontiguousarray(np.array(ranges, dtype=np.int32).reshape(-1, 2))
+        off, wo = np.array([0, n_points], dtype=np.int64), np.array([0, len(ranges)], dtype=np.int64)
+        keep, ws, ls = np.zeros(n_points, dtype=np.uint8), np.zeros(len(ranges), dtype=np.int32), np.zeros(1, dtype=np.int32)
+        check(_lib.load().gsf_gps_prefilter_chain(_ctx().handle, hptr(t), hptr(p), hptr(off), 1, hptr(wr), hptr(wo), int(max(b - a for a, b in ranges)),
+                                                  int(trials), int(need), int(degree), float(thr), 0.99, hptr(state), hptr(keep), hptr(ws), hptr(ls)))
+        if ls[0] == 0:
+            np.random.set_state((kind, state[:624], int(state[624]), has_gauss, cached))
+            if not sliding:
+                if ws[0] != 0:
+                    return times, positions                              # the fit raised: filtering skipped (ref :178-182)
+            keep = keep.astype(bool)
+            return times[keep], positions[keep]
+        # (generator untouched: `state` was a copy)
+
+    def axes_mask(t, p):
+        return _ransac_axes_mask(np.asarray(t, dtype=np.float64), np.asarray(p, dtype=np.float64), degree, need, thr, trials)
+
+    if not sliding:                                                      # ref :148-182
+        try:
+            keep = axes_mask(times, positions)
+            return times[keep], positions[keep]
+        except GsfError:
+            raise
+        except Exception:
+            return times, positions
+    keep = np.zeros(n_points, dtype=bool)
+    for rows in wins:                                                    # ref :183-247
+        try:
+            keep[rows[axes_mask(times[rows], positions[rows])]] = True
+        except GsfError:
+            raise
+        except Exception:
+            pass                                                         # a failed window marks nothing (ref :228-229)
     return times[keep], positions[keep]
 
 

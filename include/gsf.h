@@ -145,6 +145,25 @@ GSF_API int gsf_ransac_poly_batch_dev(gsf_ctx *ctx, const double *t, const doubl
                                       double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,
                                       int32_t *n_inliers, int32_t *status);
 
+/* The WHOLE pre-filter of B GNSS logs as one device chain, draws included.  Log b = rows offsets[b]..offsets[b+1] of t[] and
+   pos[][3] (UTM E, N, alt); its windows are rows win_rows[2w], win_rows[2w+1] (relative to the log's first row; found by the host
+   from the stamps, ref :205-206; one window = the whole log for the global mode, ref :148) for w in win_offsets[b]..win_offsets[b+1].
+   Per window, per axis in the reference's order: max_trials sample sets from the log's legacy MT19937 stream (mt_state[B][625],
+   in/out) exactly as scikit-learn's sample_without_replacement draws them, RANSACRegressor's acceptance walk, the stream rewound to
+   where n_trials_ draws leave it; a failing axis drops its window and consumes nothing further for it (ref :228-229).
+   keep[total] = OR over successful windows of the AND over axes; win_status[w] = 0 ok / 1 no consensus / 2 fewer rows than
+   min_samples (not processed) / 3 not handled; log_status[b] = 2 when a window's min_samples/n lies outside (0.01, 0.99) --
+   scikit-learn then samples by another method that is not restated here -- and the caller has to take the fed-sample route
+   (gsf_ransac_poly_batch_dev) for that log from its saved generator state.  max_trials <= 1024, min_samples <= 16, degree <= 3. */
+GSF_API int gsf_gps_prefilter_chain_dev(gsf_ctx *ctx, const double *t, const double *pos, const int64_t *offsets, int64_t B,
+                                        const int32_t *win_rows, const int64_t *win_offsets, int32_t max_window_rows, int32_t max_trials,
+                                        int32_t min_samples, int32_t degree, double residual_threshold, double stop_probability,
+                                        uint32_t *mt_state, uint8_t *keep, int32_t *win_status, int32_t *log_status);
+GSF_API int gsf_gps_prefilter_chain(gsf_ctx *ctx, const double *t, const double *pos, const int64_t *offsets, int64_t B,
+                                    const int32_t *win_rows, const int64_t *win_offsets, int32_t max_window_rows, int32_t max_trials,
+                                    int32_t min_samples, int32_t degree, double residual_threshold, double stop_probability,
+                                    uint32_t *mt_state, uint8_t *keep, int32_t *win_status, int32_t *log_status);
+
 /* ---- K2: Sim3 / Umeyama (compute_sim3_transform, EKFGPSSLAM.py:428-459) ------------------- */
 /* B ragged point sets: src/dst are [total][3]; offsets int64[B+1].  Optional `mask` (uint8[total], may be NULL)
    selects the rows that take part (used for "valid GNSS only" fits).  Outputs R[B][9] (row-major), t[B][3],

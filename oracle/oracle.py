@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgsf_oracle.so")
+_SO = os.environ.get("GSF_ORACLE_LIBRARY") or os.path.join(_HERE, "libgsf_oracle.so")   # override: the sanitizer build of the CPU tier
 
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -57,6 +57,8 @@ class OrcConfig(C.Structure):
 def build(force=False):
     """Compile the C restatement (gcc).  Building the checker is not using it."""
     src = os.path.join(_HERE, "gsf_oracle.c")
+    if os.environ.get("GSF_ORACLE_LIBRARY"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libgsf_oracle.so"],
                               stdout=subprocess.DEVNULL)

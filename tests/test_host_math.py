@@ -35,8 +35,9 @@ def make_cfg(cfg):
 def hh():
     bdir = os.path.join(HERE, "_build")
     os.makedirs(bdir, exist_ok=True)
-    so = os.path.join(bdir, "libhost_harness.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_harness.cpp")])
+    extra = os.environ.get("GSF_HARNESS_CXXFLAGS", "").split()          # the sanitizer run of tests/test_sanitizers_cpu.py
+    so = os.path.join(bdir, "libhost_harness_san.so" if extra else "libhost_harness.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", so, os.path.join(HERE, "host_harness.cpp")])
     L = C.CDLL(so)
     assert L.hh_ekf_config_size() == C.sizeof(EkfConfig)
     L.hh_ekf_fuse.restype = C.c_int

@@ -54,7 +54,8 @@ nt, npts, trials = 1000, 271, 1000
 bt = B.TrajectoryBatch.synthetic(nt, npts, layout=B.LAYOUT_TRAJ_MAJOR, seed=3)
 srcp = bt.pos.reshape(nt * npts, 3).contiguous(); dstp = torch.nan_to_num(bt.gps.reshape(nt * npts, 3), nan=0.0).contiguous()
 offr = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device=dev)
-idx = torch.stack([torch.stack([torch.randperm(npts, device=dev)[:4] for _ in range(trials)]) for _ in range(8)]).to(torch.int32)
+_r = np.random.default_rng(0)                                            # (host-made index sets: torch.randperm crashes under rocprofv3 --pmc)
+idx = torch.as_tensor(np.stack([np.stack([_r.permutation(npts)[:4] for _ in range(trials)]) for _ in range(8)]).astype(np.int32)).to(dev)
 idx = idx.repeat(nt // 8, 1, 1).contiguous()
 ms = timed(lambda: B.sim3_ransac_batch(srcp, dstp, offr, idx, 4.0, 4), reps=3)
 out["K2b_ransac_1000traj_271pts_1000trials"] = {"ms": ms, "traj_per_s": nt / ms * 1e3, "hypothesis_scores_per_s": nt * trials * npts / ms * 1e3}
@@ -76,7 +77,7 @@ y = 5.4e6 + 3.0 * t + 0.2 * t * t + 0.5 * torch.randn(P * n, dtype=torch.float64
 spike = torch.rand(P * n, dtype=torch.float64, device=dev, generator=g) < 0.1
 y = y + spike * 100.0
 offs = torch.arange(0, (P + 1) * n, n, dtype=torch.int64, device=dev)
-idx = torch.argsort(torch.rand(P, trials, n, device=dev, generator=g), dim=2)[:, :, :ms].to(torch.int32).contiguous()
+idx = torch.as_tensor(np.argsort(_r.random((300, trials, n)), axis=2)[:, :, :ms].astype(np.int32)).to(dev).repeat(P // 300, 1, 1).contiguous()
 ms_t = timed(lambda: B.ransac_poly_batch(t, y, offs, idx, 2, 10.0))
 out["next3_ransac_poly_30k_problems_150rows_50trials"] = {"ms": ms_t, "problems_per_s": P / ms_t * 1e3, "residual_evals_per_s": P * trials * n * 2 / ms_t * 1e3}
 del t, y, offs, idx, spike
@@ -88,4 +89,20 @@ try:
     out["next4_eval_errors_1000traj_271"] = {"ms": ms_e, "Mpairs_s": 1000 * 271 * 271 / ms_e / 1e3}
 except Exception as ex:                                                  # signature differences must not hide the other timings
     out["next4_eval_errors_1000traj_271"] = {"error": str(ex)}
+# ---- the reference's draws on the device: 1 000 streams x 1 000 trials of permutation(271)[:4]
+st = B.mt19937_seed(np.arange(1000))
+ms_c = timed(lambda: B.mt19937_choice_batch(st, [271] * 1000, 1000, 4), reps=3)
+out["mt19937_choice_1000streams_1000trials_n271"] = {"ms": ms_c, "trials_per_s": 1e6 / ms_c * 1e3, "raw_outputs_per_s_approx": 1e6 * 385 / ms_c * 1e3}
+# ---- robust chain and the chain from the geodetic log, C2 shape
+bt = B.TrajectoryBatch.synthetic(1000, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
+o = B.FusedPoses(bt.layout, 1000, 271, dev)
+ms_r = timed(lambda: B.fuse_pipeline_robust_batch(bt, st, out=o, want_mask=False), reps=3)
+out["robust_chain_1000x271"] = {"ms": ms_r, "Mposes_s": 271e3 / ms_r / 1e3}
+gb = B.GeodeticBatch.synthetic(1000, 271, seed=1)
+ms_g = timed(lambda: B.fuse_from_geodetic(gb, out=o), reps=20)
+out["geodetic_chain_1000x271"] = {"ms": ms_g, "Mposes_s": 271e3 / ms_g / 1e3}
+gb = B.GeodeticBatch.synthetic(100_000, 1000, seed=1)
+utm = torch.empty_like(gb.gps_llh); zone = torch.empty(100_000, dtype=torch.int32, device=dev); south = torch.empty_like(zone)
+ms_k = timed(lambda: _lib.check(L.gsf_gps_rows_to_utm_batch_dev(h, p(gb.gps_llh), p(gb.gps_offsets), gb.B, p(utm), p(zone), p(south))))
+out["geodesy_slice_rows_1e8"] = {"ms": ms_k, "Gpts_s": gb.gps_t.numel() / ms_k / 1e6, "alg_GBps": gb.gps_t.numel() * 48 / ms_k / 1e6}
 print(json.dumps(out, indent=1))

@@ -3,7 +3,7 @@
 usage: python tools/collect_profiles.py r01"""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw, out = os.path.join(root, "gpurun_out", "profiles_raw"), os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -15,9 +15,22 @@ if kt:
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), kt[0], f"{out}/{tag}_bench_default_by_kernel_and_grid.csv"])
 if os.path.exists(raw + "/bench_default.json"):
     shutil.copy(raw + "/bench_default.json", f"{out}/{tag}_bench_default_under_rocprof.json")
-traffic = {}
-pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel)")
-for wl in ("c2", "c3"):
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_source_hash: the profile is only quoted by bench.py while the kernels are the ones it measured)
+traffic = {"kernel_source_hash": bench.kernel_source_hash()}
+pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_duo_kernel<\w+>|ekf_wave_quad_kernel<\w+>|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
+                 r"apply_sim3_kernel|utm_kernel<\w+>|gps_rows_to_utm_kernel|enu_kernel|time_align_kernel|eval_errors_kernel|ransac_poly_kernel|mt_choice_kernel|"
+                 r"compact_valid_kernel|transpose_kernel<[\w, ]+>)")
+kt_aux = sorted(glob.glob(raw + "/trace_aux/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime, reverse=True)
+if kt_aux:
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), kt_aux[0], f"{out}/{tag}_aux_by_kernel_and_grid.csv"])
+ks_aux = sorted(glob.glob(raw + "/trace_aux/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)
+if ks_aux:
+    shutil.copy(ks_aux[0], f"{out}/{tag}_aux_kernel_stats.csv")
+if os.path.exists(raw + "/aux_kernels.json"):
+    txt = open(raw + "/aux_kernels.json").read()
+    open(f"{out}/{tag}_aux_kernels.json", "w").write(txt[txt.index("{"):])
+for wl in ("c2", "c3", "c3ekf", "aux"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{raw}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):

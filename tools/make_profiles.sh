@@ -15,3 +15,16 @@ for wl in c2 c3; do
   done
 done
 ls $OUT
+
+# 3. the auxiliary kernels (tools/bench_kernels.py): kernel trace + PMC passes
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_aux -- python3 $R/tools/bench_kernels.py > $OUT/aux_kernels.json 2> $OUT/aux_kernels.err || echo "aux trace failed"
+for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
+  n=$(echo $p | cut -d" " -f1)
+  timeout -k 10 600 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_aux_$n -- python3 $R/tools/bench_kernels.py > $OUT/pmc_aux_$n.json 2> $OUT/pmc_aux_$n.err || echo "pmc aux $n failed"
+done
+# 4. K4-only PMC at C3 (the committed C3 PMC of round 1 was of the pipeline kernel only)
+for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
+  n=$(echo $p | cut -d" " -f1)
+  timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_c3ekf_$n -- python3 $R/bench.py --workload c3 --kernel ekf --no-extra --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_c3ekf_$n.json 2> $OUT/pmc_c3ekf_$n.err || echo "pmc c3ekf $n failed"
+done
+ls $OUT
