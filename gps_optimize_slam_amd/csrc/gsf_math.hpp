@@ -85,6 +85,16 @@ GSF_HD Vec3 quat_rotate(const Quat& q, const Vec3& v)
     o.z = v.z + q.w * tz + (q.x * ty - q.y * tx);
     return o;
 }
+// as_matrix() of a unit quaternion (SciPy's form: m00 = x^2 - y^2 - z^2 + w^2, m10 = 2(xy + zw), ...).  Returned by value with
+// named members: an array filled through a pointer ends up in scratch (see the compiler notes in DESIGN.md).
+struct Mat3 { double m00, m01, m02, m10, m11, m12, m20, m21, m22; };
+GSF_HD Mat3 quat_matrix(const Quat& q)
+{
+    const double xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, ww = q.w * q.w;
+    const double xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z, xw = q.x * q.w, yw = q.y * q.w, zw = q.z * q.w;
+    return Mat3{ xx - yy - zz + ww, 2.0 * (xy - zw), 2.0 * (xz + yw), 2.0 * (xy + zw), -xx + yy - zz + ww, 2.0 * (yz - xw),
+                 2.0 * (xz - yw), 2.0 * (yz + xw), -xx - yy + zz + ww };
+}
 // as_euler('zyx')[0] of a unit quaternion: atan2(-m01, m00)
 GSF_HD double quat_yaw_zyx(const Quat& q)
 {

@@ -422,13 +422,25 @@ __device__ __forceinline__ void wave_variance_helper(const WaveArgs& a, const Ek
 // fit has been passed; everything else is identical, so the two kernels produce the same bits.
 // SMALLBATCH: the cold blocks are inlined (no far calls; ~27 more registers, which only matter when three waves per SIMD do).
 // RINGS / ring_slot: main waves per block (each owns one slice of the lane-private LDS ring).
+template <int RINGS> struct RingStore {
+    static __device__ __forceinline__ double (*get(int slot, double*))[6][64]
+    {
+        __shared__ double ring[RINGS][2][6][64];
+        return ring[RINGS > 1 ? slot : 0];
+    }
+};
+template <> struct RingStore<0> {
+    static __device__ __forceinline__ double (*get(int, double* ext))[6][64] { return (double (*)[6][64])ext; }
+};
+
+// The chunk loop of the wave-per-trajectory filter, entered with the initial pose (p0, q0) and the first 64 poses already requested
+// (nxt).  Split from the prelude so that a kernel with its own fit / initial-pose logic can fall back to it (gsf_ekf_lat.hip).
 template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1>
-__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
-                                                 const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0)
+__device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane, const int64_t base,
+                                                   const int64_t N, const Vec3& p0, const Quat& q0, const int32_t fit, ChunkIn nxt,
+                                                   const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0,
+                                                   double* ext_ring = nullptr)
 {
-    GSF_STAMP(0);
-    int64_t base, N; traj_span(a, b, base, N);
-    if (N <= 0) { if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = 0; return; }              // empty track (ref :835)
     const double* __restrict__ tsb = a.ts + base;
     const double* __restrict__ posb = a.pos + base * 3;
     const double* __restrict__ quatb = a.quat + base * 4;
@@ -436,19 +448,8 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     const uint8_t* __restrict__ valb = a.valid + base;
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
-
-    __shared__ double gsf_ring_all[RINGS][2][6][64];                     // lane-private: rows + P_f of the last two open-outage chunks
-    double (*gsf_ring)[6][64] = gsf_ring_all[RINGS > 1 ? ring_slot : 0];
-    // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
-    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
-    Vec3 p0; Quat q0; int32_t fit = 0;
-    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) {
-        if (PREVAR) __syncthreads();                                     // meet the helper wave at its barrier before leaving
-        return;
-    }
-    GSF_STAMP(6);
-    if (PREVAR) __syncthreads();                                         // the helper wave has written every chunk's variances
-
+    // lane-private ring: rows + P_f of the last two open-outage chunks (RINGS = 0: the caller provides 768 doubles of LDS)
+    double (*gsf_ring)[6][64] = RingStore<RINGS>::get(ring_slot, ext_ring);
     // ------------------------------------------------------------------ carry (wave-uniform, replicated in every lane)
     Quat cq = ekf_normalize(q0);                                         // ref :842, :683
     Vec3 cp = p0;
@@ -703,6 +704,32 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
         GSF_STAMP(8 + (int)(c0 / 64));
     }
     if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
+}
+
+template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1>
+__device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
+                                                 const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0)
+{
+    GSF_STAMP(0);
+    int64_t base, N; traj_span(a, b, base, N);
+    if (N <= 0) { if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = 0; return; }              // empty track (ref :835)
+    const double* __restrict__ tsb = a.ts + base;
+    const double* __restrict__ posb = a.pos + base * 3;
+    const double* __restrict__ quatb = a.quat + base * 4;
+    const double* __restrict__ gpsb = a.gps + base * 3;
+    const uint8_t* __restrict__ valb = a.valid + base;
+
+    // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
+    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
+    Vec3 p0; Quat q0; int32_t fit = 0;
+    if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) {
+        if (PREVAR) __syncthreads();                                     // meet the helper wave at its barrier before leaving
+        return;
+    }
+    GSF_STAMP(6);
+    if (PREVAR) __syncthreads();                                         // the helper wave has written every chunk's variances
+
+    wave_serial_chunks<PIPELINE, PREVAR, SMALLBATCH, RINGS>(a, cfg, b, lane, base, N, p0, q0, fit, nxt, pv, pv_stride, ring_slot);
 }
 
 
