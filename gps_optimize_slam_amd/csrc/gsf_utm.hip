@@ -2,9 +2,10 @@
 // EKFGPSSLAM.py:266-271, and utm_to_wgs84, :291-296) plus the zone pick of auto_utm_projection (:127-134).
 //
 // One lane per point, SoA lat[]/lon[] so a wave reads two contiguous 512-B rows and writes two.
-// This kernel is FP64-VALU-bound, not HBM-bound (~10 libm-class calls per point against 32 B of
-// traffic): the Krueger series is evaluated with angle-addition recurrences so that only one
-// sincos and one exp are paid for the six harmonics (gsf_math.hpp: tm_series).
+// This kernel is FP64-VALU-bound, not HBM-bound (profiles/r02_pmc_aux.txt: ~420 VALU instructions per point, 82 % of the issue
+// slots of the launch, against 32 B of traffic): three libm-class calls are left on the forward side (sincos of the latitude,
+// sincos of the longitude difference, one atan2), everything else is short series and angle-addition recurrences
+// (gsf_math.hpp: utm_forward_point, tm_series).
 #include "gsf_internal.hpp"
 
 using namespace gsf;

@@ -5,10 +5,11 @@ Same function names, argument order, return conventions and error behaviour as t
 quaternions scalar-last.  Every numerical stage runs on the GPU through libgsf.so -- there is no
 CPU fallback: without the library / a device the first call raises GsfError.
 
-What stays host Python, as in the reference: text I/O (np.loadtxt/np.savetxt), the RNG draws of the
-Sim3 RANSAC (np.random.choice on the legacy global stream, so a seeded run reproduces the
-reference's), and -- until its device kernel lands -- the optional sklearn GPS outlier
-filter.  The time alignment (next-1) is a device kernel (gsf_time_align_batch).
+What stays host Python, as in the reference: text I/O (np.loadtxt/np.savetxt) and the walk over the window stamps of the GPS
+pre-filter.  The reference's random draws (np.random.choice of the Sim3 RANSAC, scikit-learn's sampler in the pre-filter) are
+made ON THE DEVICE from NumPy's global legacy generator state, which is handed back advanced exactly as the reference leaves
+it, so a seeded run reproduces the reference's rows.  Time alignment, the pre-filter's polynomial RANSAC and the error metric
+are device kernels too.
 """
 import copy
 import ctypes as C

@@ -19,17 +19,13 @@ t0 = time.time()
 po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
 print(f"oracle {time.time() - t0:.1f} s; status histogram {np.bincount(sto, minlength=32)[:16].tolist()}", flush=True)
 worst = 0.0
-for name, layout, opt in (("wave (default)", 0, None), ("lane (time-major)", 1, None), ("block", 0, ("ekf_variant", 8)), ("single-shot", 0, ("seg_kernel", 1))):
-    if opt and opt[0] == "seg_kernel" and N > 320:
-        continue
-    if opt and opt[0] == "ekf_variant" and N > 1024:
-        continue
+for name, layout, opt in (("wave (default)", 0, None), ("time-major via the wave kernel", 1, None), ("lane (time-major)", 1, ("lane_min_traj", 0))):
     batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
     if opt: B.context().set_option(*opt)
     try:
         p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
     finally:
-        if opt: B.context().set_option(opt[0], 0)
+        if opt: B.context().set_option(opt[0], 32768)
     bad = np.nonzero(st != sto)[0]
     dp, dq = np.abs(p - po).max(), np.abs(q - qo).max()
     worst = max(worst, dp)
