@@ -1,5 +1,5 @@
-"""The bench.py output contract, checked on the committed sample line (profiles/r01_bench_default_under_rocprof.json: the default
-`python bench.py` run of make_profiles.sh on an MI355X) and on bench.py's own constants -- CPU tier, no GPU needed."""
+"""The bench.py output contract, checked on the committed sample line (profiles/r02_bench_default_under_rocprof.json: the default
+`python bench.py` run of make_profiles.sh on an MI355X) and on bench.py's own constants and helpers -- CPU tier, no GPU needed."""
 import ast
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -26,7 +26,51 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "fused poses/s" and c["sample"]
-    assert d["max_abs_pos_err_m"] < 1e-6 and d["status_bits_equal"] is True
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0 and c["cpu_model"]
+    # the gate is on the TIMED outputs of the timed kernel, and the reference's own error metric agrees between GPU and CPU results
+    assert d["max_abs_pos_err_m"] < 1e-6 and d["status_bits_equal"] is True and d["gated"].startswith("timed fused-pipeline outputs")
+    q = d["ref_style_error_q15"]
+    assert q["max_abs_diff_m"] < 1e-6 and q["trajectories"] > 0
+    assert r["kernel_source_hash"] and (r["traffic"] is None) == (not str(r["traffic_source"]).endswith("_traffic.json"))
+    assert abs(r["frac_of_peak_on_moved_bytes"] - r["moved_bytes_per_launch_incl_fit_pass"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-12
+    e = d["extra"]
+    assert e["pcie_inclusive"]["poses_per_s"] < d["value"] and e["c1_drop_in"]["end_to_end_ms"]["best"] > 0
+    assert e["robust_chain_c2"]["ms"] > 0 and e["geodetic_chain_c2"]["ms"] > 0
+
+
+def test_committed_traffic_profile_matches_the_kernel_sources():
+    """bench.py only quotes profiles/rNN_traffic.json while the kernels are the ones the profile measured."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    assert doc["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/make_profiles.sh + tools/collect_profiles.py after changing a kernel"
+    got, src = bench.profiled_traffic("c2", "ekf_wave_quad_kernel<true>", 128000)
+    assert src == "r02_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
+
+
+def test_spawned_ranks_use_loopback_and_fresh_processes(monkeypatch):
+    """`bench.py --gpus N` without a launcher: N child processes with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR=127.0.0.1, the parent
+    itself imports neither torch nor the library (checked by running spawn_ranks with a stub interpreter)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = []
+
+    class P:
+        def __init__(self, cmd, env=None, stdout=None):
+            seen.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+            self.returncode = 0
+        def communicate(self):
+            return (b'{"ok": 1}\n', None)
+        def wait(self, timeout=None):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", P)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
+    assert "torch" not in bench.__dict__
+    assert bench.spawn_ranks(3) == 0
+    assert [e["RANK"] for _, e in seen] == ["0", "1", "2"] and all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for _, e in seen)
+    assert len({e["MASTER_PORT"] for _, e in seen}) == 1 and all(c[1].endswith("bench.py") and c[2:] == ["--gpus", "3", "--steps", "2"] for c, _ in seen)
 
 
 def test_bench_constants():
