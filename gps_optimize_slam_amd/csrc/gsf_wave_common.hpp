@@ -470,6 +470,13 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
     Quat c_r; bool c_ok = quat_unit(lane_bcast(nxt.q, 0), c_r);
     double c_t = lane_bcast(nxt.t, 0);
     int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
+    // Orientation on the fast path.  With every quaternion valid the increments telescope to q_i = Cq r_i, Cq = q_carry conj(r_carry),
+    // and Cq is the SAME rotation for the whole track (q_carry = Cq r_L, so the next chunk's q_carry conj(r_carry) = Cq r_L conj(r_L)
+    // = Cq): it is formed once and pinned in SGPRs; the carried state quaternion is only materialised (cq_fresh) for a chunk that has
+    // to take the generic path.
+    const Quat cq0 = cq;
+    Quat Cq = lane_bcast(quat_mul(cq, quat_conj(c_r)), 0);
+    bool cq_fresh = true;
     for (int64_t c0 = 0; c0 < N; c0 += 64) {
         const int64_t i = c0 + lane;
         const bool active = i < N;
@@ -501,6 +508,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
         Vec3 dpl{ 0.0, 0.0, 0.0 }; Quat dq{ 0.0, 0.0, 0.0, 1.0 };
         if (!telescope) {                                                // calculate_relative_pose, ref :77-92
+            if (!cq_fresh) { cq = quat_mul(Cq, c_r); cq_fresh = true; }  // the state quaternion the telescoped chunks did not carry
             const Quat r1i = quat_conj(prev_lane(c_r, r));
             dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
             dq = quat_mul(r1i, r);
@@ -553,11 +561,14 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         // ---- orientation (ref :708-709) and predicted displacement (ref :707)
         Quat qi; Vec3 u;
         if (telescope) {
-            const Quat Cq = quat_mul(cq, quat_conj(c_r));
             // normalize_quaternion (ref :697-700) is the identity here up to rounding: Cq and r are unit quaternions (every
             // quaternion of the chunk passed quat_unit), so |Cq r| = 1 +- 2e-16 and its "norm > 1e-9" guard cannot fire.  The
-            // product is written out as it is; the carried cq picks up at most one rounding of the norm per CHUNK.
-            qi = is_init ? cq : quat_mul(Cq, r);
+            // product is written out as it is.
+            qi = quat_mul(Cq, r);
+            if (c0 == 0) {                                               // wave-uniform: pose 0 keeps the initial state (ref :842)
+                qi.x = is_init ? cq0.x : qi.x; qi.y = is_init ? cq0.y : qi.y; qi.z = is_init ? cq0.z : qi.z; qi.w = is_init ? cq0.w : qi.w;
+            }
+            cq_fresh = false;
             u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
             u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
         } else {
@@ -689,7 +700,11 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
             }
         }
         c_prev_avail = !open;
-        cq = lane_bcast(qi, L);
+        if (!telescope) {                                                // (the fast path carries no state quaternion: see Cq above)
+            cq = lane_bcast(qi, L);
+            const Quat rL = lane_bcast(r, L);
+            if (((ok_mask >> L) & 1ull) != 0ull) Cq = lane_bcast(quat_mul(cq, quat_conj(rL)), 0);
+        }
         cp = Vec3{ cp.x + lane_bcast(xl[0], L), cp.y + lane_bcast(xl[1], L), cp.z + lane_bcast(xl[2], L) };
         cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
         c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
