@@ -201,8 +201,9 @@ def profiled_traffic(workload, kernel, grid_threads):
 # ----------------------------------------------------------------------------------------------------------------------
 # C5-shaped leg: fuse a big per-GPU shard chunk by chunk, all-gather every chunk's poses while the next chunk is fused
 # ----------------------------------------------------------------------------------------------------------------------
-def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N, passes=1):
+def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N, passes=1, stall_cb=None, stall_seconds=240.0):
     import ctypes as C
+    import threading
 
     from gps_optimize_slam_amd import _lib
     L = _lib.load()
@@ -278,15 +279,28 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
     exp_all = int(D.all_reduce(local_sum.clone().reshape(1)).item())      # wrapping int64 sum of every rank's checksum
     recv_per_rank = (world - 1) * T * N * 56
     legs = [("torch_all_gather", None)]
-    collector = None
     if not rehearsal:
-        try:
-            collector = D.PoseCollector(dev, s_comm)
-            legs += [("gsf_ncclAllGather", 0), ("gsf_direct_sendrecv", 1)]
-        except Exception as e:                                             # symmetric: every rank resolves the same library
-            info["own_communicator_error"] = str(e)[:200]
+        legs += [("gsf_ncclAllGather", 0), ("gsf_direct_sendrecv", 1)]
+    collector, watchdog = None, None
     info["collect"] = {}
     for name, mode in legs:
+        if mode is not None and collector is None:
+            # The library's own communicator has never met a second GPU before an 8-GPU node runs this (one GPU per build box).  A
+            # watchdog guards the legs that use it: if set-up or an exchange stalls, every rank reports what it has (rank 0 prints
+            # the JSON line through stall_cb) and leaves -- the torch.distributed leg above is already in `info`.
+            def on_stall():
+                info["own_communicator_error"] = f"watchdog: the library's RCCL communicator did not finish within {stall_seconds:.0f} s"
+                if stall_cb is not None:
+                    stall_cb(info)
+                os._exit(0)
+            watchdog = threading.Timer(stall_seconds, on_stall)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                collector = D.PoseCollector(dev, s_comm)
+            except Exception as e:                                         # symmetric: every rank resolves the same library
+                info["own_communicator_error"] = str(e)[:200]
+                break
         def gather(k):                                                     # on s_comm
             send = out[k * P * 7:(k + 1) * P * 7]
             if mode is None:
@@ -324,6 +338,8 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
                                  "gathered_checksum_equals_sum_of_rank_checksums": bool(ok)}
     if collector is not None:
         collector.close()
+    if watchdog is not None:
+        watchdog.cancel()
     del batch, out, recv
     torch.cuda.empty_cache()
     return info
@@ -372,9 +388,10 @@ def worker(args):
     # ------------------------------------------------------------------------------------------------ C5 as the headline
     if args.workload == "c5":
         chunk = args.chunk_traj or (32768 if not rehearsal else 1024)
-        info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps))
-        if rank == 0:
-            best = min(info["collect"].values(), key=lambda c: c["pass_ms"]) if world > 1 else None
+        def emit_c5(info):
+            if rank != 0:
+                return
+            best = min(info["collect"].values(), key=lambda c: c["pass_ms"]) if world > 1 and info.get("collect") else None
             pass_ms = best["pass_ms"] if best else info["compute_only"]["ms"]
             T = info["trajectories_per_gpu"]
             co = info["compute_only"]
@@ -387,7 +404,9 @@ def worker(args):
                                     "frac": co["hbm_frac"], "traffic": None, "traffic_note": "no PMC pass at this size", "alg_bytes_per_launch": info["chunk_trajectories"] * N * ALG_BYTES_PER_POSE,
                                     "kernel_ms": co["ms"] / info["chunks"]},
                           c5=info)
-            print(json.dumps(result))
+            print(json.dumps(result), flush=True)
+        info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps), stall_cb=emit_c5)
+        emit_c5(info)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -517,8 +536,12 @@ def worker(args):
         # C5-shaped leg (BASELINE configs[4]): the per-GPU shard of 10M x 1k over 8 GPUs, chunked fuse + overlapped all-gather
         tpg = args.traj_per_gpu or (WORKLOADS["c5"]["B"] if not rehearsal else 4096)
         chunk = args.chunk_traj or (32768 if not rehearsal else 1024)
+        def emit_with_c5(info):
+            if rank == 0:
+                result["c5"] = info
+                print(json.dumps(result), flush=True)
         try:
-            info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"])
+            info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5)
         except Exception as e:                  # sizes are symmetric over ranks, so a failure (e.g. out of memory) is too
             info = {"error": f"{type(e).__name__}: {e}"[:300]}
         result["c5"] = info

@@ -19,7 +19,7 @@ using namespace gsf;
 
 namespace {
 
-constexpr int RP_THREADS = 128;        // >= max_trials
+constexpr int RP_THREADS = 128;        // trials are strided over the threads
 constexpr int RP_MAX_SAMPLES = 16;
 constexpr int RP_MAX_DEGREE = 3;
 
@@ -92,24 +92,28 @@ __device__ __forceinline__ double dynamic_max_trials(int n_inliers, int n_sample
     return fabs(ceil(log(nom) / log(denom)));
 }
 
+constexpr int RP_MAX_TRIALS = 1024;
 __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* __restrict__ t, const double* __restrict__ y,
                                                                   const int64_t* __restrict__ offsets, const int32_t* __restrict__ sample_idx,
                                                                   int max_trials, int ms, int degree, double thr, double stop_prob,
                                                                   uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_trials,
                                                                   int32_t* __restrict__ n_inliers, int32_t* __restrict__ status)
 {
-    __shared__ int sh_nin[RP_THREADS];
-    __shared__ double sh_score[RP_THREADS];
+    __shared__ int sh_nin[RP_MAX_TRIALS];
+    __shared__ double sh_score[RP_MAX_TRIALS];
     __shared__ int sh_best;
     const int64_t p = blockIdx.x;
     const int64_t i0 = offsets[p], i1 = offsets[p + 1];
     const int n = (int)(i1 - i0);
     const double* tp = t + i0; const double* yp = y + i0;
-    const int tau = threadIdx.x;
-    PolyModel m;
-    m.coef[0] = m.coef[1] = m.coef[2] = 0.0; m.intercept = 0.0;
-    if (tau < max_trials && n > 0) {
-        m = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + tau) * ms, ms, degree);
+    bool bad_index = false;
+    // trials strided over the threads; a caller-fed sample set naming a row outside [0, n) is never accepted and is flagged
+    for (int tau = threadIdx.x; tau < max_trials && n > 0; tau += RP_THREADS) {
+        const int32_t* idx = sample_idx + ((int64_t)p * max_trials + tau) * ms;
+        bool in_range = true;
+        for (int k = 0; k < ms; ++k) in_range = in_range && idx[k] >= 0 && idx[k] < n;
+        if (!in_range) { bad_index = true; sh_nin[tau] = -1; sh_score[tau] = NAN; continue; }
+        const PolyModel m = fit_subset(tp, yp, idx, ms, degree);
         // |y - y_pred| <= threshold over all rows (ref loss "absolute_error"), then r2_score of the model on its inliers
         int cnt = 0; double sy = 0.0;
 #pragma unroll 8                                                          // rows are wave-uniform scalar loads: keep several in flight
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
         }
         sh_nin[tau] = cnt; sh_score[tau] = score;
     }
-    __syncthreads();
-    if (tau == 0) {
+    const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
+    if (threadIdx.x == 0) {
         // RANSACRegressor.fit's loop over the trials, in order (sklearn/linear_model/_ransac.py)
         int best = -1, best_n = 1, ntr = 0;
         double best_score = -INFINITY, max_tr = (double)max_trials;
@@ -147,10 +151,11 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
             }
         }
         sh_best = best;
-        n_trials[p] = ntr; n_inliers[p] = best >= 0 ? best_n : 0; status[p] = best >= 0 ? 0 : 1;
+        n_trials[p] = ntr; n_inliers[p] = best >= 0 ? best_n : 0; status[p] = (best >= 0 ? 0 : 1) | (any_bad ? 2 : 0);
     }
     __syncthreads();
     const int best = sh_best;
+    const int tau = threadIdx.x;
     if (best < 0) { for (int i = tau; i < n; i += RP_THREADS) inlier_mask[i0 + i] = 0; return; }
     // every thread re-fits the accepted sample set (6 rows) and marks its share of the rows
     const PolyModel mb = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + best) * ms, ms, degree);
@@ -288,7 +293,7 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
 {
     GSF_REQUIRE(ctx && offsets && inlier_mask && n_trials && n_inliers && status, "NULL argument");
     GSF_REQUIRE(P >= 0 && P <= 0x7fffffff, "bad P");
-    GSF_REQUIRE(max_trials >= 1 && max_trials <= RP_THREADS, "max_trials must be in [1,128]");
+    GSF_REQUIRE(max_trials >= 1 && max_trials <= RP_MAX_TRIALS, "max_trials must be in [1,1024]");
     GSF_REQUIRE(min_samples >= 1 && min_samples <= RP_MAX_SAMPLES, "min_samples must be in [1,16]");
     GSF_REQUIRE(degree >= 1 && degree <= RP_MAX_DEGREE, "polynomial degree must be in [1,3]");
     GSF_REQUIRE(sample_idx, "sample_idx is NULL");

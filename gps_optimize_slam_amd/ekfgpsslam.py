@@ -138,7 +138,7 @@ def _ransac_axes_mask(t, p, degree, min_samples, residual_threshold, max_trials)
         rs.set_state(state)
         for _ in range(ntr):
             sample_without_replacement(n, min_samples, random_state=rs)
-        if st != 0:
+        if st & 1:
             raise ValueError("RANSAC could not find a valid consensus set.")
         keep &= mask.cpu().numpy().astype(bool)
     return keep

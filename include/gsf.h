@@ -139,7 +139,8 @@ GSF_API int gsf_geodetic_to_enu_batch_dev(gsf_ctx *ctx, const double *lat_deg, c
    sample_without_replacement on NumPy's legacy RNG (the call of sklearn/linear_model/_ransac.py), so a seeded run reproduces the
    reference.  Per problem: inlier_mask over its rows (|y - poly(t)| <= residual_threshold for the accepted model), n_trials (the
    number of sample sets scikit-learn's loop would have consumed: acceptance rule + dynamic trial count with stop_probability),
-   n_inliers, status (0 = ok, 1 = no consensus set: the reference's ValueError).  degree 1..3, min_samples <= 16, max_trials <= 128. */
+   n_inliers, status (bit 0: no consensus set -- the reference's ValueError; bit 1: a fed sample set named a row outside the problem
+   and was skipped).  degree 1..3, min_samples <= 16, max_trials <= 1024. */
 GSF_API int gsf_ransac_poly_batch_dev(gsf_ctx *ctx, const double *t, const double *y, const int64_t *offsets, int64_t P,
                                       const int32_t *sample_idx, int32_t max_trials, int32_t min_samples, int32_t degree,
                                       double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,

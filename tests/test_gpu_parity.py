@@ -843,6 +843,31 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
+def test_fed_sample_sets_are_validated_and_trials_stride(B):
+    """caller-fed row indices outside [0, n) must not be dereferenced (K2b and the polynomial RANSAC skip such a sample
+    set and flag it), and max_trials above the block size is strided over the threads (200 trials on 128 threads)."""
+    import torch
+    rng = np.random.default_rng(0)
+    n, trials = 120, 200
+    tt = np.arange(n) * 0.1
+    y = 3.0 + 0.5 * tt + 0.02 * tt * tt + rng.normal(size=n) * 0.05
+    y[::11] += 30.0
+    idx = np.stack([rng.permutation(n)[:6] for _ in range(trials)]).astype(np.int32)
+    td, yd = torch.as_tensor(tt).cuda(), torch.as_tensor(y).cuda()
+    offs = torch.tensor([0, n], dtype=torch.int64).cuda()
+    mask, ntr, nin, st = B.ransac_poly_batch(td, yd, offs, torch.as_tensor(idx.reshape(1, trials, 6)).cuda(), 2, 1.0)
+    assert int(st.item()) == 0 and int(nin.item()) >= n - 12 and 1 <= int(ntr.item()) <= trials
+    bad = idx.copy(); bad[0, 2] = n + 5; bad[3, 0] = -1
+    mask2, ntr2, nin2, st2 = B.ransac_poly_batch(td, yd, offs, torch.as_tensor(bad.reshape(1, trials, 6)).cuda(), 2, 1.0)
+    assert int(st2.item()) == 2 and int(nin2.item()) >= n - 12                     # flagged, still a consensus set from the valid trials
+    # K2b
+    src = rng.normal(size=(n, 3)).cumsum(axis=0); dst = 1.1 * src + np.array([10.0, -3.0, 2.0]) + rng.normal(size=(n, 3)) * 0.01
+    sidx = np.stack([rng.permutation(n)[:4] for _ in range(64)]).astype(np.int32)
+    sidx[5, 1] = n; sidx[6, 3] = -7
+    R, t, s, stt, m, ni = B.sim3_ransac_batch(torch.as_tensor(src).cuda(), torch.as_tensor(dst).cuda(), offs, torch.as_tensor(sidx.reshape(1, 64, 4)).cuda(), 1.0, 4)
+    assert int(stt.item()) & 8 and not int(stt.item()) & 1 and abs(float(s.item()) - 1.1) < 1e-3
+
+
 def test_device_chain_from_geodetic_log_vs_oracle(B, orc):
     """K1 (mask, zone pick, UTM forward) -> time alignment -> fit -> EKF+RTS from a ragged geodetic GNSS log without leaving the
     device, against the oracle chained the same way (load_gps_data's geodesy slice :258-271, dynamic_time_alignment :325-387,
