@@ -243,15 +243,18 @@ def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask
 
 
 def sim3_umeyama_batch(src, dst, offsets=None, mask=None):
-    """K2 over device tensors.  src/dst: (total,3) with int64 offsets (B+1,), or (B,W,3) equal-size windows.
+    """K2 over device tensors.  src/dst: (total,3) with int64 offsets (B+1,), or (B,W,3) equal-size windows (config C4; mask (B,W)).
     Returns R (B,9), t (B,3), s (B,), status (B,) int32."""
+    f = dict(dtype=torch.float64, device=src.device)
     if src.dim() == 3:
         B, W, _ = src.shape
-        offsets = torch.arange(0, (B + 1) * W, W, dtype=torch.int64, device=src.device)
-        src, dst = src.reshape(B * W, 3), dst.reshape(B * W, 3)
+        _chk(src, torch.float64, (B, W, 3), "src"); _chk(dst, torch.float64, (B, W, 3), "dst")
+        R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
+        st = torch.empty((B,), dtype=torch.int32, device=src.device)
+        check(_lib.load().gsf_sim3_umeyama_windows_dev(context().handle, _p(src), _p(dst), _p(mask), B, W, _p(R), _p(t), _p(s), _p(st)))
+        return R, t, s, st
     B = offsets.numel() - 1
     _chk(src, torch.float64, src.shape, "src"); _chk(dst, torch.float64, src.shape, "dst")
-    f = dict(dtype=torch.float64, device=src.device)
     R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
     st = torch.empty((B,), dtype=torch.int32, device=src.device)
     check(_lib.load().gsf_sim3_umeyama_batch_dev(context().handle, _p(src), _p(dst), _p(mask), _p(offsets), B, _p(R), _p(t), _p(s), _p(st)))

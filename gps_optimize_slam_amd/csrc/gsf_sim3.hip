@@ -185,6 +185,119 @@ __global__ __launch_bounds__(64) void umeyama_batch_kernel(const double* __restr
     s[b] = sb; status[b] = st;
 }
 
+// ---- equal-size windows (config C4: 1 M windows of 50 point pairs), split in two launches so that the STREAMING part runs at
+// high occupancy without the SVD's registers:
+//   windows_moments_kernel   one 16-lane DPP row per window: shifted raw moments of its W rows (rows read once), the 16 sums of a row
+//                            reduced by a transposing butterfly (15 exchanges instead of 16 four-stage scans), one 192-byte record
+//                            per window written by the row's lanes;
+//   windows_finalize_kernel  lane per window: H, centroids, 3x3 Jacobi SVD, R / t / s (the ~900-instruction tail, paid once per
+//                            64 windows and overlapping nothing it could stall).
+constexpr int WIN_REC = 24;            // doubles per record: 16 sums (Sa3 Sb3 Saa Sab9) | as3 bs3 | n | pad
+
+// sixteen row-local sums at once: after the four exchange stages lane l of a 16-lane row holds the row total of value index
+// bitrev4(l & 15) (the same butterfly as wave_sum16, without the cross-row adds)
+__device__ __forceinline__ double row_sum16(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7,
+                                            double a8, double a9, double a10, double a11, double a12, double a13, double a14, double a15, int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+#define GSF_BFLY(bit, lo_, hi_, XCHG) ((bit ? hi_ : lo_) + XCHG(bit ? lo_ : hi_))
+    const double w0 = GSF_BFLY(b0, a0, a8, dpp_quad<0xB1>), w1 = GSF_BFLY(b0, a1, a9, dpp_quad<0xB1>), w2 = GSF_BFLY(b0, a2, a10, dpp_quad<0xB1>),
+                 w3 = GSF_BFLY(b0, a3, a11, dpp_quad<0xB1>), w4 = GSF_BFLY(b0, a4, a12, dpp_quad<0xB1>), w5 = GSF_BFLY(b0, a5, a13, dpp_quad<0xB1>),
+                 w6 = GSF_BFLY(b0, a6, a14, dpp_quad<0xB1>), w7 = GSF_BFLY(b0, a7, a15, dpp_quad<0xB1>);
+    const double x0 = GSF_BFLY(b1, w0, w4, dpp_quad<0x4E>), x1 = GSF_BFLY(b1, w1, w5, dpp_quad<0x4E>), x2 = GSF_BFLY(b1, w2, w6, dpp_quad<0x4E>),
+                 x3 = GSF_BFLY(b1, w3, w7, dpp_quad<0x4E>);
+    const double y0 = GSF_BFLY(b2, x0, x2, dpp_row_xor<4>), y1 = GSF_BFLY(b2, x1, x3, dpp_row_xor<4>);
+    return GSF_BFLY(b3, y0, y1, dpp_row_xor<8>);
+#undef GSF_BFLY
+}
+
+__global__ void window_offsets_kernel(int64_t* off, int64_t B, int64_t W)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= B) off[b] = b * W;
+}
+
+__global__ __launch_bounds__(256) void windows_moments_kernel(const double* __restrict__ src, const double* __restrict__ dst,
+                                                              const uint8_t* __restrict__ mask, int64_t B, int W, double* __restrict__ rec)
+{
+    const int lane = threadIdx.x & 63, j0 = lane & 15;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int brev = ((j0 & 1) << 3) | ((j0 & 2) << 1) | ((j0 & 4) >> 1) | ((j0 & 8) >> 3);
+    for (int64_t w = group; w < ((B + 3) & ~(int64_t)3); w += ngroups) {   // whole waves iterate together (four windows per wave and trip)
+        const bool live = w < B;
+        const int64_t i0 = (live ? w : B - 1) * (int64_t)W, i1 = live ? i0 + W : i0;
+        // shift = the first usable row of the window: row 0 unless it is masked out or not finite
+        double as0 = src[i0 * 3], as1 = src[i0 * 3 + 1], as2 = src[i0 * 3 + 2], bs0 = dst[i0 * 3], bs1 = dst[i0 * 3 + 1], bs2 = dst[i0 * 3 + 2];
+        bool have = live && (!mask || mask[i0] != 0) && (fabs(as0) < INFINITY) && (fabs(as1) < INFINITY) && (fabs(as2) < INFINITY) &&
+                    (fabs(bs0) < INFINITY) && (fabs(bs1) < INFINITY) && (fabs(bs2) < INFINITY);
+        if (__ballot(live && !have) != 0ull) {                            // rare: search the window for its first usable row
+            const int gbase = lane & 48;
+            for (int64_t off = 0; __ballot(live && !have && i0 + off < i1) != 0ull; off += 16) {
+                const int64_t i = i0 + off + j0;
+                bool ok = live && i < i1 && !have;
+                double a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
+                if (ok) {
+                    ok = !mask || mask[i] != 0;
+                    a0 = src[i * 3]; a1 = src[i * 3 + 1]; a2 = src[i * 3 + 2]; c0 = dst[i * 3]; c1 = dst[i * 3 + 1]; c2 = dst[i * 3 + 2];
+                    ok = ok && (fabs(a0) < INFINITY) && (fabs(a1) < INFINITY) && (fabs(a2) < INFINITY) && (fabs(c0) < INFINITY) &&
+                         (fabs(c1) < INFINITY) && (fabs(c2) < INFINITY);
+                }
+                const u64 m = __ballot(ok);
+                const unsigned field = (unsigned)(m >> gbase) & 0xffffu;
+                const int srcl = gbase + (field ? __ffs((int)field) - 1 : 0);
+                const double f0 = shidx(a0, srcl), f1 = shidx(a1, srcl), f2 = shidx(a2, srcl), g0 = shidx(c0, srcl), g1 = shidx(c1, srcl), g2 = shidx(c2, srcl);
+                if (!have && field) { as0 = f0; as1 = f1; as2 = f2; bs0 = g0; bs1 = g1; bs2 = g2; have = true; }
+            }
+        }
+        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+        double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int64_t i = i0 + j0; i < i1; i += 16) {                      // (two slices per trip with the loads up front: no faster, measured)
+            if (!mask || mask[i] != 0) {
+                const double a0 = src[i * 3] - as0, a1 = src[i * 3 + 1] - as1, a2 = src[i * 3 + 2] - as2;
+                const double c0 = dst[i * 3] - bs0, c1 = dst[i * 3 + 1] - bs1, c2 = dst[i * 3 + 2] - bs2;
+                cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += c0; Sb1 += c1; Sb2 += c2;
+                Saa += a0 * a0 + a1 * a1 + a2 * a2;
+                Sab[0] += a0 * c0; Sab[1] += a0 * c1; Sab[2] += a0 * c2;
+                Sab[3] += a1 * c0; Sab[4] += a1 * c1; Sab[5] += a1 * c2;
+                Sab[6] += a2 * c0; Sab[7] += a2 * c1; Sab[8] += a2 * c2;
+            }
+        }
+        const double tot = row_sum16(Sa0, Sa1, Sa2, Sb0, Sb1, Sb2, Saa, Sab[0], Sab[1], Sab[2], Sab[3], Sab[4], Sab[5], Sab[6], Sab[7], Sab[8], lane);
+        const double n = row16_scan_sum(cnt);                             // total in lane 15 of the row
+        if (live) {
+            double* r = rec + w * WIN_REC;
+            r[brev] = tot;                                                // lane l holds sum index bitrev4(l)
+            const double tail = (j0 == 0) ? as0 : (j0 == 1) ? as1 : (j0 == 2) ? as2 : (j0 == 3) ? bs0 : (j0 == 4) ? bs1 : bs2;
+            if (j0 < 6) r[16 + j0] = tail;
+            if (j0 == 15) r[22] = have ? n : 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void windows_finalize_kernel(const double* __restrict__ rec, int64_t B, double* __restrict__ R, double* __restrict__ t,
+                                                              double* __restrict__ s, int32_t* __restrict__ status)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const double* r = rec + b * WIN_REC;
+    RawMoments m;
+    m.Sa[0] = r[0]; m.Sa[1] = r[1]; m.Sa[2] = r[2]; m.Sb[0] = r[3]; m.Sb[1] = r[4]; m.Sb[2] = r[5]; m.Saa = r[6];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m.Sab[k] = r[7 + k];
+    m.as[0] = r[16]; m.as[1] = r[17]; m.as[2] = r[18]; m.bs[0] = r[19]; m.bs[1] = r[20]; m.bs[2] = r[21]; m.n = r[22];
+    double Rb[9], tb[3], sb = NAN;
+    const int32_t st = finalize_raw(m, Rb, tb, sb);
+    if (st == SIM3_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rb[k] = NAN;
+        tb[0] = tb[1] = tb[2] = NAN; sb = NAN;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[b * 9 + k] = Rb[k];
+    t[b * 3] = tb[0]; t[b * 3 + 1] = tb[1]; t[b * 3 + 2] = tb[2];
+    s[b] = sb; status[b] = st;
+}
+
 // ------------------------------------------------------------------------------------------------
 constexpr int RANSAC_THREADS = 256;
 constexpr int RANSAC_MAX_SAMPLES = 8;
@@ -430,6 +543,35 @@ int gsf_sim3_umeyama_batch_dev(gsf_ctx* ctx, const double* src, const double* ds
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(umeyama_batch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, src, dst, mask, offsets, B, R, t, s, status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+int gsf_sim3_umeyama_windows_dev(gsf_ctx* ctx, const double* src, const double* dst, const uint8_t* mask, int64_t B, int32_t W, double* R, double* t,
+                                 double* s, int32_t* status)
+{
+    GSF_REQUIRE(ctx && R && t && s && status, "NULL argument");
+    GSF_REQUIRE(B >= 0 && W >= 0, "negative B or W");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(W == 0 || (src && dst), "NULL points");
+    GSF_HIP(hipSetDevice(ctx->device));
+    if (W == 0 || W > 4096) {                                             // empty windows (all None) / long windows: the ragged kernel on generated offsets
+        int rc = ensure_scratch(ctx, (size_t)(B + 1) * 8);
+        if (rc) return rc;
+        int64_t* off = (int64_t*)ctx->scratch;
+        hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned)((B + 256) / 256)), dim3(256), 0, ctx->stream, off, B, (int64_t)W);
+        GSF_HIP(hipGetLastError());
+        return gsf_sim3_umeyama_batch_dev(ctx, src, dst, mask, off, B, R, t, s, status);
+    }
+    int rc = ensure_scratch(ctx, (size_t)B * WIN_REC * 8);
+    if (rc) return rc;
+    double* rec = (double*)ctx->scratch;
+    const int64_t groups = (B + 3) / 4 * 4;                               // one 16-lane row per window and trip; grid-stride beyond 64 k blocks
+    int64_t blocks = (groups * 16 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(windows_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, src, dst, mask, B, (int)W, rec);
+    GSF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(windows_finalize_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, rec, B, R, t, s, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

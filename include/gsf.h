@@ -171,6 +171,11 @@ GSF_API int gsf_gps_prefilter_chain(gsf_ctx *ctx, const double *t, const double 
    s[B], status[B]. */
 GSF_API int gsf_sim3_umeyama_batch_dev(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask,
                                const int64_t *offsets, int64_t B, double *R, double *t, double *s, int32_t *status);
+/* B equal-size windows of W point pairs each (BASELINE config C4: sliding-window re-alignment, 1 M windows of 50 pairs):
+   src/dst are [B][W][3], mask (may be NULL) [B][W].  Same results as gsf_sim3_umeyama_batch_dev on offsets b*W; the streaming
+   moments pass and the per-window 3x3 SVD run as two launches (a 192-byte record per window in the context's workspace). */
+GSF_API int gsf_sim3_umeyama_windows_dev(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask, int64_t B, int32_t W,
+                                         double *R, double *t, double *s, int32_t *status);
 GSF_API int gsf_sim3_umeyama_batch(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask,
                            const int64_t *offsets, int64_t B, double *R, double *t, double *s, int32_t *status);
 

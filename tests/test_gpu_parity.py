@@ -332,6 +332,22 @@ def test_umeyama_windows_vs_oracle(B, orc):
         np.testing.assert_allclose(R[b].reshape(3, 3), Ro, atol=1e-10, rtol=0)
         assert abs(s[b] - so) < 1e-11
         np.testing.assert_allclose(s[b] * src[b] @ R[b].reshape(3, 3).T + t[b], so * src[b] @ Ro.T + to, atol=POS_TOL, rtol=0)
+    # the equal-size-window entry (two launches) against the ragged kernel on the same windows, incl. masked rows, a window whose
+    # first rows are masked out / NaN (shift search), windows with fewer than 3 usable rows, and a window count that is not a multiple of 4
+    nbw = 1003
+    sw, dw = torch.as_tensor(src[:nbw].copy()).cuda(), torch.as_tensor(dst[:nbw].copy()).cuda()
+    mk = torch.ones((nbw, W), dtype=torch.uint8).cuda()
+    mk[3, :5] = 0; mk[4, :] = 0; mk[5, 2:] = 0; mk[7, ::2] = 0
+    sw[8, 0, 1] = float("nan"); mk[8, 0] = 1
+    Rw, tw, s_w, stw = B.sim3_umeyama_batch(sw, dw, mask=mk)
+    offw = torch.arange(0, (nbw + 1) * W, W, dtype=torch.int64).cuda()
+    Rr, tr, sr, str_ = B.sim3_umeyama_batch(sw.reshape(-1, 3), dw.reshape(-1, 3), offw, mk.reshape(-1))
+    np.testing.assert_array_equal(stw.cpu().numpy(), str_.cpu().numpy())
+    assert stw[4].item() == 1 and stw[5].item() == 1 and stw[3].item() == 0
+    okw = (stw == 0).cpu().numpy() & np.isfinite(Rr.cpu().numpy()).all(axis=1)
+    np.testing.assert_allclose(Rw.cpu().numpy()[okw], Rr.cpu().numpy()[okw], atol=1e-11, rtol=0)
+    np.testing.assert_allclose(s_w.cpu().numpy()[okw], sr.cpu().numpy()[okw], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(tw.cpu().numpy()[okw], tr.cpu().numpy()[okw], atol=1e-6, rtol=0)
     # ragged + masked + too-short sets
     offs = torch.tensor([0, 2, 2, 60, 200], dtype=torch.int64).cuda()
     flat_s, flat_d = torch.as_tensor(src.reshape(-1, 3)[:200].copy()).cuda(), torch.as_tensor(dst.reshape(-1, 3)[:200].copy()).cuda()
