@@ -93,27 +93,34 @@ __device__ __forceinline__ double dynamic_max_trials(int n_inliers, int n_sample
 }
 
 constexpr int RP_MAX_TRIALS = 1024;
-__global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* __restrict__ t, const double* __restrict__ y,
-                                                                  const int64_t* __restrict__ offsets, const int32_t* __restrict__ sample_idx,
-                                                                  int max_trials, int ms, int degree, double thr, double stop_prob,
-                                                                  uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_trials,
-                                                                  int32_t* __restrict__ n_inliers, int32_t* __restrict__ status)
+// THREADS >= max_trials: one thread per trial.  (Trials strided over a fixed block in a loop -- even a template-unrolled one -- made
+// the two inlined fit_subset copies spill twice as much to scratch: 1.26 -> 2.15 ms per 30 000 problems.  A wider block for more than
+// 128 trials keeps the single-pass shape.)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ransac_poly_kernel(const double* __restrict__ t, const double* __restrict__ y,
+                                                               const int64_t* __restrict__ offsets, const int32_t* __restrict__ sample_idx,
+                                                               int max_trials, int ms, int degree, double thr, double stop_prob,
+                                                               uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_trials,
+                                                               int32_t* __restrict__ n_inliers, int32_t* __restrict__ status)
 {
-    __shared__ int sh_nin[RP_MAX_TRIALS];
-    __shared__ double sh_score[RP_MAX_TRIALS];
+    __shared__ int sh_nin[THREADS];
+    __shared__ double sh_score[THREADS];
     __shared__ int sh_best;
     const int64_t p = blockIdx.x;
     const int64_t i0 = offsets[p], i1 = offsets[p + 1];
     const int n = (int)(i1 - i0);
     const double* tp = t + i0; const double* yp = y + i0;
-    bool bad_index = false;
-    // trials strided over the threads; a caller-fed sample set naming a row outside [0, n) is never accepted and is flagged
-    for (int tau = threadIdx.x; tau < max_trials && n > 0; tau += RP_THREADS) {
-        const int32_t* idx = sample_idx + ((int64_t)p * max_trials + tau) * ms;
-        bool in_range = true;
-        for (int k = 0; k < ms; ++k) in_range = in_range && idx[k] >= 0 && idx[k] < n;
-        if (!in_range) { bad_index = true; sh_nin[tau] = -1; sh_score[tau] = NAN; continue; }
-        const PolyModel m = fit_subset(tp, yp, idx, ms, degree);
+    const int tau = threadIdx.x;
+    PolyModel m;
+    m.coef[0] = m.coef[1] = m.coef[2] = 0.0; m.intercept = 0.0;
+    // a caller-fed sample set naming a row outside [0, n) is never accepted and is flagged (status bit 1)
+    bool in_range = true;
+    if (tau < max_trials && n > 0) {
+        const int32_t* ix = sample_idx + ((int64_t)p * max_trials + tau) * ms;
+        for (int k = 0; k < ms; ++k) in_range = in_range && ix[k] >= 0 && ix[k] < n;
+    }
+    if (tau < max_trials && n > 0 && in_range) {
+        m = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + tau) * ms, ms, degree);
         // |y - y_pred| <= threshold over all rows (ref loss "absolute_error"), then r2_score of the model on its inliers
         int cnt = 0; double sy = 0.0;
 #pragma unroll 8                                                          // rows are wave-uniform scalar loads: keep several in flight
@@ -133,9 +140,9 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
             score = ss_tot != 0.0 ? 1.0 - ss_res / ss_tot : (ss_res == 0.0 ? 1.0 : 0.0);   // force_finite
         }
         sh_nin[tau] = cnt; sh_score[tau] = score;
-    }
-    const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
-    if (threadIdx.x == 0) {
+    } else if (tau < max_trials && n > 0) { sh_nin[tau] = -1; sh_score[tau] = NAN; }
+    const bool any_bad = __syncthreads_or(in_range ? 0 : 1) != 0;
+    if (tau == 0) {
         // RANSACRegressor.fit's loop over the trials, in order (sklearn/linear_model/_ransac.py)
         int best = -1, best_n = 1, ntr = 0;
         double best_score = -INFINITY, max_tr = (double)max_trials;
@@ -155,11 +162,10 @@ __global__ __launch_bounds__(RP_THREADS) void ransac_poly_kernel(const double* _
     }
     __syncthreads();
     const int best = sh_best;
-    const int tau = threadIdx.x;
-    if (best < 0) { for (int i = tau; i < n; i += RP_THREADS) inlier_mask[i0 + i] = 0; return; }
+    if (best < 0) { for (int i = tau; i < n; i += THREADS) inlier_mask[i0 + i] = 0; return; }
     // every thread re-fits the accepted sample set (6 rows) and marks its share of the rows
     const PolyModel mb = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + best) * ms, ms, degree);
-    for (int i = tau; i < n; i += RP_THREADS) inlier_mask[i0 + i] = fabs(yp[i] - poly_predict(mb, degree, tp[i])) <= thr ? 1 : 0;
+    for (int i = tau; i < n; i += THREADS) inlier_mask[i0 + i] = fabs(yp[i] - poly_predict(mb, degree, tp[i])) <= thr ? 1 : 0;
 }
 
 // score of one fed trial (steps 1 of the header comment) for rows with a stride (AoS position rows)
@@ -299,8 +305,10 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
     GSF_REQUIRE(sample_idx, "sample_idx is NULL");
     if (P == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(ransac_poly_kernel, dim3((unsigned)P), dim3(RP_THREADS), 0, ctx->stream, t, y, offsets, sample_idx, (int)max_trials,
-                       (int)min_samples, (int)degree, residual_threshold, stop_probability, inlier_mask, n_trials, n_inliers, status);
+#define GSF_LAUNCH_RP(THREADS_) hipLaunchKernelGGL(ransac_poly_kernel<THREADS_>, dim3((unsigned)P), dim3(THREADS_), 0, ctx->stream, t, y, offsets, sample_idx, (int)max_trials, \
+                       (int)min_samples, (int)degree, residual_threshold, stop_probability, inlier_mask, n_trials, n_inliers, status)
+    if (max_trials <= 128) GSF_LAUNCH_RP(128); else if (max_trials <= 256) GSF_LAUNCH_RP(256); else if (max_trials <= 512) GSF_LAUNCH_RP(512); else GSF_LAUNCH_RP(1024);
+#undef GSF_LAUNCH_RP
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

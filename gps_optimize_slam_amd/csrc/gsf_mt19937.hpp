@@ -79,10 +79,15 @@ __device__ __forceinline__ void mt_draw_choice(uint32_t* mt, int& pos, const int
                 unsigned long long acc = __ballot(have);
                 int ik = 0; uint32_t u = 0;
                 for (int it = 0; it < 65; ++it) {
-                    ik = i - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
+                    // two refinement passes per convergence test (a pass is ~10 VALU instructions, the test a VALU -> SALU -> branch
+                    // round trip): the second pass of a converged pattern reproduces it
+                    int i1 = i - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
+                    uint32_t u1 = (i1 >= 1) ? (y & mask_for((uint32_t)i1)) : 0u;
+                    const unsigned long long mid = __ballot(have && i1 >= 1 && u1 <= (uint32_t)i1);
+                    ik = i - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mid >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mid, 0u));
                     u = (ik >= 1) ? (y & mask_for((uint32_t)ik)) : 0u;
                     const unsigned long long nxt = __ballot(have && ik >= 1 && u <= (uint32_t)ik);
-                    if (nxt == acc) break;
+                    if (nxt == mid) { acc = nxt; break; }
                     acc = nxt;
                 }
                 // the trial ends with the acceptance that takes i to 0: outputs after it belong to the next trial
@@ -101,15 +106,31 @@ __device__ __forceinline__ void mt_draw_choice(uint32_t* mt, int& pos, const int
         }
         __syncthreads();
         // ---- trace phase: x[p] after the shuffle = the start position reached by undoing the swaps i = 1 .. n-1 from position p
-        for (int task = lane; task < nt * kk; task += 64) {
-            const int tb = task / kk, p = task - tb * kk;
-            const uint16_t* js = jseq + (size_t)tb * n;
-            int at = p;
-            for (int i = 1; i < n; ++i) {
-                const int j = js[i];
-                at = (at == i) ? j : ((at == j) ? i : at);
+        if (kk <= 4 && nt * 2 <= 64 + 63) {
+            // up to four heads: lane (trial, half) traces two positions through one read of every swap partner
+            for (int task = lane; task < nt * 2; task += 64) {
+                const int tb = task >> 1, p0 = (task & 1) * 2;
+                const uint16_t* js = jseq + (size_t)tb * n;
+                int a0 = p0, a1 = p0 + 1;
+                for (int i = 1; i < n; ++i) {
+                    const int j = js[i];
+                    a0 = (a0 == i) ? j : ((a0 == j) ? i : a0);
+                    a1 = (a1 == i) ? j : ((a1 == j) ? i : a1);
+                }
+                if (p0 < kk) out[(size_t)(t0 + tb) * kk + p0] = a0;
+                if (p0 + 1 < kk) out[(size_t)(t0 + tb) * kk + p0 + 1] = a1;
             }
-            out[(size_t)(t0 + tb) * kk + p] = at;
+        } else {
+            for (int task = lane; task < nt * kk; task += 64) {
+                const int tb = task / kk, p = task - tb * kk;
+                const uint16_t* js = jseq + (size_t)tb * n;
+                int at = p;
+                for (int i = 1; i < n; ++i) {
+                    const int j = js[i];
+                    at = (at == i) ? j : ((at == j) ? i : at);
+                }
+                out[(size_t)(t0 + tb) * kk + p] = at;
+            }
         }
         __syncthreads();
     }
