@@ -458,12 +458,10 @@ def worker(args):
     poses_per_step = world * Bn * N
     alg_bytes = Bn * N * ALG_BYTES_PER_POSE
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; all three produce identical bits)
+    # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
     pipe = args.kernel == "pipeline"
-    if pipe and 64 < N <= 384 and 512 < Bn <= 1024:
-        kernel_name, grid_threads = "ekf_wave_quad_kernel<true>", ((Bn + 3) // 4) * 512       # four trajectories per 512-thread block, helper waves
-    elif pipe and 64 < N <= 640 and Bn <= 512:
-        kernel_name, grid_threads = "ekf_wave_duo_kernel<true>", Bn * 128
+    if pipe and 64 < N <= 640 and Bn <= 256:
+        kernel_name, grid_threads = "ekf_wave_duo_kernel<true>", Bn * 128                     # a helper wave per trajectory
     else:
         kernel_name, grid_threads = "ekf_wave_kernel<%s, %s>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
     traffic, traffic_src = profiled_traffic(args.workload, kernel_name, grid_threads)

@@ -203,7 +203,7 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     GSF_REQUIRE(ctx && key, "NULL argument");
     if (strcmp(key, "ekf_variant") == 0) { ctx->ekf_variant = (int)value; return GSF_OK; }
     if (strcmp(key, "duo_kernel") == 0) {
-        if (value < -1 || value > 2) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 (one wave), 1 (two-wave blocks) or 2 (four-trajectory blocks)"); return GSF_ERR_INVALID_ARG; }
+        if (value < -1 || value > 1) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 (one wave) or 1 (two-wave blocks)"); return GSF_ERR_INVALID_ARG; }
         ctx->duo_kernel = (int)value; return GSF_OK;
     }
     if (strcmp(key, "lane_min_traj") == 0) {

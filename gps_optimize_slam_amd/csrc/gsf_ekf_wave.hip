@@ -55,29 +55,6 @@ __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig
     wave_serial_body<PIPELINE, true, true>(a, cfg, b, lane, gsf_pv, pv_stride);
 }
 
-// The same split with the pairing FORCED: four trajectories per 512-thread block.  Measured on MI355X (tools/ubench/placement.hip):
-// the eight waves of a 512-thread block go to the four SIMDs of ONE CU in the order s0 s1 s2 s3 s0 s1 s2 s3, so main wave k and
-// helper wave k + 4 share a SIMD, and a grid of <= 256 such blocks puts exactly one block on every CU: every SIMD then holds one
-// main and one helper wave and no two main waves ever compete for a SIMD (with 128-thread blocks that pairing is left to the
-// dispatcher: clean tracks took 14.5-18.8 us at 1 000 tracks depending on whether two main waves shared a SIMD).
-template <bool PIPELINE>
-__global__ __launch_bounds__(512) void ekf_wave_quad_kernel(WaveArgs a, EkfConfig cfg, int pv_stride)
-{
-    extern __shared__ double gsf_pv[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, slot = w & 3;
-    const bool helper = w >= 4;
-    const int64_t b = (int64_t)blockIdx.x * 4 + slot;
-    double* pv = gsf_pv + (size_t)slot * 9 * (size_t)pv_stride;
-    if (a.N <= 0) { if (!helper && b < a.B && lane == 0 && a.status) a.status[b] = 0; return; }   // empty tracks: every wave leaves before any barrier
-    if (b >= a.B) { __syncthreads(); return; }                            // idle pair of the last block: meet the one barrier
-    if (helper) {
-        wave_variance_helper(a, cfg, b, lane, pv, pv_stride);
-        __syncthreads();
-        return;
-    }
-    wave_serial_body<PIPELINE, true, true, 4>(a, cfg, b, lane, pv, pv_stride, slot);
-}
-
 EkfConfig to_core(const gsf_ekf_config* c)
 {
     EkfConfig k;
@@ -104,22 +81,11 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     const EkfConfig k = to_core(cfg);
     // small batches of the fused pipeline: two waves per trajectory (see ekf_wave_duo_kernel).  Bit-identical to the one-wave
     // kernel, so choosing by batch size does not break shard invariance.  gsf_set_option "duo_kernel": -1 automatic, 0 never, 1 always.
-    // Measured (pipeline, N = 271): 17.5 vs 20.8 us at 250 tracks, 20.8 vs 21.9 us at 500; at 1 000 tracks within +-3 % of the one-wave
-    // kernel depending on the batch (22.4 vs 23.3 us on one, 24.6 vs 24.0 us on the bench's), slower from 2 000 on (every SIMD
-    // then holds several waves anyway) -- automatic = up to 768 tracks.
-    // 512 < B <= 1 024 tracks of <= 384 poses: the four-trajectory form (one block per CU, main + helper of a trajectory on one SIMD).
-    // "duo_kernel" 2 forces it.
-    if (pipeline && !offsets && ctx->duo_kernel != 0 && N > 64 && N <= 384 && (ctx->duo_kernel == 2 || (ctx->duo_kernel == -1 && B > 512 && B <= 1024))) {
-        const int stride = (int)((N + 1) & ~(int64_t)1);
-        const size_t lds = (size_t)stride * 9 * sizeof(double) * 4;
-        static bool attr_set = false;
-        if (!attr_set) { GSF_HIP(hipFuncSetAttribute((const void*)ekf_wave_quad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL(ekf_wave_quad_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(512), lds, ctx->stream, a, k, stride);
-        GSF_HIP(hipGetLastError());
-        return GSF_OK;
-    }
-    if (pipeline && !offsets && ctx->duo_kernel != 0 && ctx->duo_kernel != 2 && N > 64 && N <= 640 &&
-        (ctx->duo_kernel == 1 || B <= 512)) {
+    // Measured with the polar-iteration fit (pipeline, N = 271; tools/scratch-style sweep in DESIGN 5): 15.5 vs 17.8 us at 256 tracks,
+    // 19.4 vs 18.9 us at 512, 20.9 vs 19.5 us at 1 000 (every SIMD then holds a main wave and the helper only competes with it)
+    // -- automatic = up to 256 tracks.  The four-trajectory-per-block form of round 2 (main and helper of a trajectory forced onto
+    // one SIMD) lost its edge with the shorter fit (20.2 vs 19.5 us at 1 000) and lives in tools/experiments/ now.
+    if (pipeline && !offsets && ctx->duo_kernel != 0 && N > 64 && N <= 640 && (ctx->duo_kernel == 1 || (ctx->duo_kernel == -1 && B <= 256))) {
         const int stride = (int)((N + 1) & ~(int64_t)1);
         hipLaunchKernelGGL(ekf_wave_duo_kernel<true>, dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
         GSF_HIP(hipGetLastError());

@@ -19,7 +19,6 @@ using namespace gsf;
 
 namespace {
 
-constexpr int RP_THREADS = 128;        // trials are strided over the threads
 constexpr int RP_MAX_SAMPLES = 16;
 constexpr int RP_MAX_DEGREE = 3;
 

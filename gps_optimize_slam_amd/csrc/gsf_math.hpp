@@ -54,6 +54,24 @@ GSF_HD double fast_rsqrt(double a)
 #endif
 }
 
+// the bare hardware seeds (~2^-26 relative): for factors whose accuracy only steers an iteration
+GSF_HD double seed_rcp(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(a);
+#else
+    return 1.0 / a;
+#endif
+}
+GSF_HD double seed_rsqrt(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(a);
+#else
+    return 1.0 / sqrt(a);
+#endif
+}
+
 // Rotation.from_quat: q/|q|; false if the norm is 0/NaN/inf (SciPy raises ValueError).
 GSF_HD bool quat_unit(const Quat& q, Quat& o)
 {
@@ -224,11 +242,130 @@ GSF_HD void svd3(const double* H, Svd3& out)
     out.U[2] = sg * c0; out.U[5] = sg * c1; out.U[8] = sg * c2;
 }
 
+// ---------------------------------------------------------------------------------------
+// The rotation and the singular-value sum of the Umeyama closed form WITHOUT an SVD, for the fused pipeline's latency-bound
+// prelude (one trajectory per wave: the Jacobi SVD above is ~1 150 dependent instructions, this is ~400 / ~530).
+//   Vt.T @ U.T (ref :440) is the transpose of the orthogonal polar factor Q = U V^T of H, and S0+S1+S2 = trace(Q^T H).
+//   Q by Newton's iteration X <- (g X + (1/g) X^-T)/2 from X0 = H/|H|_F with X^-T = cof(X)/det(X) (3x3 cofactors), three steps
+//   with Frobenius scaling g and four plain ones.  X and cof(X) share their singular vectors, so the accuracy of the two
+//   coefficients only steers convergence (hardware seeds suffice); the last step takes a full-precision 1/det.  Measured against
+//   a 40-digit SVD on 400 track-shaped H with sigma1/sigma3 from 3e3 to 2e14: |Q - Q_true| <= 2.9e-15 (NumPy's own SVD: 1e-13).
+//   det(H) < 0 (ref :441-442: the last row of Vt is negated) is R = (I - 2 v3 v3^T) Q^T with v3 the right singular vector of
+//   sigma3: cof(X0) = +-sum (sigma_j sigma_k) u_i v_i^T is dominated by u3 v3^T up to e = sigma3/sigma2.  For e < 3e-3 (the
+//   usual case) three steps of x <- cof^T (cof x) from its largest row (e^7); up to e = 0.33, B = cof^T cof squared five times
+//   (e^64).  A track whose vertical direction is noise has det(H) < 0 half of the time and e up to a few 0.1, so this case is not
+//   rare and has to be as cheap as the other.  (Rayleigh-quotient steps on P = Q^T H were tried: with sigma2/sigma1 ~ 1e-6 --
+//   straight tracks -- the adjugate of P - rho I loses the direction again: 4e-14 after the power steps, 7e-12 after two steps.)
+// Returns false -- the caller then takes the SVD -- for H that is zero / non-finite, singular to working precision, whose
+// reflection direction is not separated (sigma3/sigma2 > 0.33), or if the iteration did not land on an orthogonal matrix.
+// ---------------------------------------------------------------------------------------
+GSF_HD void cof3(const double* X, double* C)                               // C = det(X) X^-T
+{
+    C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+    C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+    C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+}
+GSF_HD double sumsq9(const double* M)
+{
+    return M[0] * M[0] + M[1] * M[1] + M[2] * M[2] + M[3] * M[3] + M[4] * M[4] + M[5] * M[5] + M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma)
+{
+    const double nh2 = sumsq9(H);
+    if (!(nh2 > 1e-280 && nh2 < 1e280)) return false;
+    const double rn = fast_rsqrt(nh2);
+    double X[9], C[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X[i] = H[i] * rn;
+    // ---- step 1 (scaled) and the reflection direction, both from cof(X0)
+    cof3(X, C);
+    double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+    double nc2 = sumsq9(C);
+    if (!(det * det > 1e-28 * nc2)) return false;                          // sigma3 < 1e-14 sigma1 (also rank <= 1, NaN)
+    const bool reflect = det < 0.0;
+    double v[3] = { 0.0, 0.0, 0.0 };
+    if (reflect) {                                                         // wave-uniform in the pipeline
+        const double e0 = fabs(det);                                       // e0 / nc2 >= sigma3 / sigma2  (|X0|_F = 1: sigma1 <= 1)
+        if (!(e0 < 0.3 * nc2)) return false;                               // e / (1 + e^2) < 0.3: e < 0.33, e^64 < 1e-30
+        if (e0 < 3e-3 * nc2) {
+            // well separated (the usual case): the largest row of cof, three steps of x <- cof^T (cof x)  (e^7 < 1e-17)
+            const double r0 = C[0] * C[0] + C[1] * C[1] + C[2] * C[2], r1 = C[3] * C[3] + C[4] * C[4] + C[5] * C[5],
+                         r2 = C[6] * C[6] + C[7] * C[7] + C[8] * C[8];
+            const bool p1 = r1 > r0 && r1 >= r2, p2 = r2 > r0 && r2 > r1;
+            v[0] = p2 ? C[6] : (p1 ? C[3] : C[0]); v[1] = p2 ? C[7] : (p1 ? C[4] : C[1]); v[2] = p2 ? C[8] : (p1 ? C[5] : C[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double w0 = C[0] * v[0] + C[1] * v[1] + C[2] * v[2], w1 = C[3] * v[0] + C[4] * v[1] + C[5] * v[2],
+                             w2 = C[6] * v[0] + C[7] * v[1] + C[8] * v[2];
+                v[0] = C[0] * w0 + C[3] * w1 + C[6] * w2; v[1] = C[1] * w0 + C[4] * w1 + C[7] * w2; v[2] = C[2] * w0 + C[5] * w1 + C[8] * w2;
+            }
+        } else {
+            // weakly separated (e up to 0.33): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
+            // that v3 v3^T dominates by e^64; v3 is its largest column
+            double b00 = C[0] * C[0] + C[3] * C[3] + C[6] * C[6], b01 = C[0] * C[1] + C[3] * C[4] + C[6] * C[7],
+                   b02 = C[0] * C[2] + C[3] * C[5] + C[6] * C[8], b11 = C[1] * C[1] + C[4] * C[4] + C[7] * C[7],
+                   b12 = C[1] * C[2] + C[4] * C[5] + C[7] * C[8], b22 = C[2] * C[2] + C[5] * C[5] + C[8] * C[8];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double rt = seed_rcp(b00 + b11 + b22);
+                b00 *= rt; b01 *= rt; b02 *= rt; b11 *= rt; b12 *= rt; b22 *= rt;
+                const double c00 = b00 * b00 + b01 * b01 + b02 * b02, c01 = b00 * b01 + b01 * b11 + b02 * b12,
+                             c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12,
+                             c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
+                b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
+            }
+            const bool p1 = b11 > b00 && b11 >= b22, p2 = b22 > b00 && b22 > b11;   // the largest diagonal entry names the largest column
+            v[0] = p2 ? b02 : (p1 ? b01 : b00); v[1] = p2 ? b12 : (p1 ? b11 : b01); v[2] = p2 ? b22 : (p1 ? b12 : b02);
+        }
+        const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        if (!(vn2 > 1e-290)) return false;
+        const double rv = fast_rsqrt(vn2);
+        v[0] *= rv; v[1] *= rv; v[2] *= rv;
+    }
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        if (it > 0) { cof3(X, C); det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2]; }
+        double a, b;
+        if (it < 3) {
+            // g^2 = sqrt(nc2 / nx2) / |det|:  a = g / 2,  b = 1 / (2 g det) = a sign(det) sqrt(nx2 / nc2)
+            if (it > 0) nc2 = sumsq9(C);
+            const double nx2 = sumsq9(X);
+            const double q = nc2 * seed_rcp(nx2), rq = seed_rsqrt(q);       // rq = sqrt(nx2 / nc2)
+            a = 0.5 * ((q * rq) * seed_rsqrt(q * rq)) * seed_rsqrt(fabs(det));   // sqrt(sqrt(q)) / sqrt|det| / 2
+            b = reflect ? -(a * rq) : a * rq;
+        } else {
+            a = 0.5;
+            b = 0.5 * (it == 6 ? fast_rcp(det) : seed_rcp(det));
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) X[i] = a * X[i] + b * C[i];
+    }
+    if (!(fabs(sumsq9(X) - 3.0) < 1e-12)) return false;
+    sum_sigma = X[0] * H[0] + X[1] * H[1] + X[2] * H[2] + X[3] * H[3] + X[4] * H[4] + X[5] * H[5] + X[6] * H[6] + X[7] * H[7] + X[8] * H[8];
+    if (!reflect) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = X[c * 3 + r];
+    } else {
+        const double w0 = X[0] * v[0] + X[1] * v[1] + X[2] * v[2], w1 = X[3] * v[0] + X[4] * v[1] + X[5] * v[2],
+                     w2 = X[6] * v[0] + X[7] * v[1] + X[8] * v[2];                  // Q v3 (= u3)
+        const double w[3] = { w0, w1, w2 };
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = X[c * 3 + r] - 2.0 * v[r] * w[c];
+    }
+    return true;
+}
+
 // status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
 enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8 };
 
 // Umeyama closed form from the reduced moments, ref :439-451.
 //   H = sum src_c dst_c^T (row-major), ssq = sum |src_c|^2, sc/dc centroids, n points.
+// POLAR: take the rotation from umeyama_rotation_polar when it applies (the fused pipeline; identical to the SVD route to ~1e-14).
+template <bool POLAR = false>
 GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, const double* dc, double n,
                                 double* R, double* t, double& scale)
 {
@@ -236,22 +373,25 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
 #pragma unroll
     for (int i = 0; i < 9; ++i) finite = finite && (fabs(H[i]) < INFINITY);   // NaN/inf -> LinAlgError -> None (:452)
     if (!finite) return SIM3_NONE;
-    Svd3 s; svd3(H, s);
-    // R = Vt.T @ U.T = V U^T                                                   (:440)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] + s.V[r * 3 + 2] * s.U[c * 3 + 2];
-    if (det3(R) < 0.0) {                                                       // (:441-442) flip last row of Vt
+    double tr = 0.0;
+    if (!(POLAR && umeyama_rotation_polar(H, R, tr))) {                        // tr: S0+S1+S2 (det(R) = 1 to rounding, Q12)
+        Svd3 s; svd3(H, s);
+        // R = Vt.T @ U.T = V U^T                                               (:440)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] - s.V[r * 3 + 2] * s.U[c * 3 + 2];
+                R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] + s.V[r * 3 + 2] * s.U[c * 3 + 2];
+        if (det3(R) < 0.0) {                                                   // (:441-442) flip last row of Vt
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] - s.V[r * 3 + 2] * s.U[c * 3 + 2];
+        }
+        tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                               // (:444, Q12)
     }
     double var_src = ssq / n;                                                  // (:443)
-    double tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                            // (:444, Q12)
     int32_t flags = SIM3_OK;
     if (var_src < 1e-12) { scale = 1.0; flags |= SIM3_FLAG_VAR0; }             // (:445-447)
     else {

@@ -161,15 +161,26 @@ __device__ __forceinline__ void traj_span(const WaveArgs& a, int64_t b, int64_t&
 #ifndef GSF_TIMING_B
 #define GSF_TIMING_B 0
 #endif
-#define GSF_STAMP(k) do { if (b == GSF_TIMING_B && lane == 0 && a.status) { a.status[2 * (k)] = (int32_t)(clock64() & 0x7fffffff); a.status[2 * (k) + 1] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+// The stamps are parked in LDS and written out when the wave is done: a global store behind every stamp stalls the next VALU
+// write to its source registers until the memory pipeline has taken the store, which under the input burst took microseconds and
+// showed up as a phantom gap after the prelude.
+__device__ __forceinline__ int32_t* gsf_stamp_buf() { __shared__ int32_t buf[64]; return buf; }
+#define GSF_STAMP(k) do { if (b == GSF_TIMING_B && lane == 0) { int32_t* sb_ = gsf_stamp_buf(); sb_[2 * (k)] = (int32_t)(clock64() & 0x7fffffff); sb_[2 * (k) + 1] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#define GSF_STAMP_FLUSH() do { if (b == GSF_TIMING_B && lane == 0 && a.status) { const int32_t* sb_ = gsf_stamp_buf(); for (int k_ = 0; k_ < 32; ++k_) a.status[k_] = sb_[k_]; } } while (0)
 #define GSF_STATUS_PTR(a) ((int32_t*)nullptr)
 #elif defined(GSF_WAVE_START_TIMING)
 // diagnostic build only (tools/wave_start_timing.py): EVERY wave writes the 100 MHz clock at its entry (stamp 0) and at its last
 // chunk (stamp 8 + last chunk) into status[b] / status[B + b]; no real status words in this build
-#define GSF_STAMP(k) do { if (lane == 0 && a.status) { if ((k) == 0) a.status[b] = (int32_t)(wall_clock64() & 0x7fffffff); else if ((k) >= 8) a.status[a.B + b] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#ifndef GSF_WT_FIRST
+#define GSF_WT_FIRST 0                                                   // stamp index recorded into status[b] ...
+#define GSF_WT_SECOND 8                                                  // ... and (every index >= this one) into status[B + b]
+#endif
+#define GSF_STAMP(k) do { if (lane == 0 && a.status) { if ((k) == GSF_WT_FIRST) a.status[b] = (int32_t)(wall_clock64() & 0x7fffffff); else if (((k) == GSF_WT_SECOND || (GSF_WT_SECOND == 8 && (k) > 8)) && (k) < 13) a.status[a.B + b] = (int32_t)(wall_clock64() & 0x7fffffff); } } while (0)
+#define GSF_STAMP_FLUSH() do { } while (0)
 #define GSF_STATUS_PTR(a) ((int32_t*)nullptr)
 #else
 #define GSF_STAMP(k) do { } while (0)
+#define GSF_STAMP_FLUSH() do { } while (0)
 #define GSF_STATUS_PTR(a) ((a).status)
 #endif
 
@@ -227,7 +238,11 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
         for (int k = 0; k < 9; ++k) H[k] = S.v[7 + k] - n * ma[k / 3] * mb[k % 3];
         const double sc[3] = { as_[0] + ma[0], as_[1] + ma[1], as_[2] + ma[2] }, dc[3] = { bs_[0] + mb[0], bs_[1] + mb[1], bs_[2] + mb[2] };
         GSF_STAMP(3);
-        fit = umeyama_finalize(H, ssq, sc, dc, n, Rb, tb, sb);           // every lane redundantly (wave-uniform inputs)
+#ifdef GSF_FIT_SVD                                                        // A/B build (make ab): the Jacobi SVD route
+        fit = umeyama_finalize<false>(H, ssq, sc, dc, n, Rb, tb, sb);
+#else
+        fit = umeyama_finalize<true>(H, ssq, sc, dc, n, Rb, tb, sb);     // every lane redundantly (wave-uniform inputs)
+#endif
         GSF_STAMP(4);
     }
     Quat qn0; const bool q0ok = quat_unit(qraw0, qn0);
@@ -296,6 +311,10 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
                     pa[k][0] = pa[k][1] = pa[k][2] = 0.0; pz[k][0] = pz[k][1] = pz[k][2] = 0.0; pv[k] = 0u;
                 }
             }
+            // the mask bytes stay opaque until every load of the round is issued: left alone, the compiler turns each byte into a lane
+            // mask right behind its load (one VGPR less) and thereby waits for memory once per 64 rows instead of once per round
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) asm volatile("" : "+v"(pv[k]));
             bool ok[MOM_ROUND];
 #pragma unroll
             for (int k = 0; k < MOM_ROUND; ++k)
@@ -718,6 +737,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         }
         GSF_STAMP(8 + (int)(c0 / 64));
     }
+    GSF_STAMP_FLUSH();
     if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }
 
@@ -736,6 +756,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
 
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
     ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
+    __builtin_amdgcn_sched_barrier(0);                                   // ... and stay requested HERE: nothing of the prelude is scheduled above them
     Vec3 p0; Quat q0; int32_t fit = 0;
     if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) {
         if (PREVAR) __syncthreads();                                     // meet the helper wave at its barrier before leaving

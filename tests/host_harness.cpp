@@ -46,7 +46,7 @@ int hh_ekf_fuse(const double* ts, const double* pos, const double* quat, const d
     return f.finish();
 }
 
-int hh_umeyama(const double* src, const double* dst, int64_t n, double* R, double* t, double* s)
+static int umeyama_impl(const double* src, const double* dst, int64_t n, double* R, double* t, double* s, bool polar)
 {
     if (n < 3) return SIM3_NONE;
     double sc[3] = { 0, 0, 0 }, dc[3] = { 0, 0, 0 };
@@ -59,8 +59,13 @@ int hh_umeyama(const double* src, const double* dst, int64_t n, double* R, doubl
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r * 3 + c] += a[r] * b[c];
         ssq += a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
     }
-    return umeyama_finalize(H, ssq, sc, dc, (double)n, R, t, *s);
+    return polar ? umeyama_finalize<true>(H, ssq, sc, dc, (double)n, R, t, *s) : umeyama_finalize(H, ssq, sc, dc, (double)n, R, t, *s);
 }
+int hh_umeyama(const double* src, const double* dst, int64_t n, double* R, double* t, double* s) { return umeyama_impl(src, dst, n, R, t, s, false); }
+// the fused pipeline's route (Newton polar iteration instead of the SVD where it applies)
+int hh_umeyama_polar(const double* src, const double* dst, int64_t n, double* R, double* t, double* s) { return umeyama_impl(src, dst, n, R, t, s, true); }
+// 1 if umeyama_rotation_polar accepts H (else the SVD route is taken)
+int hh_polar_applies(const double* H) { double R[9], tr; return umeyama_rotation_polar(H, R, tr) ? 1 : 0; }
 
 void hh_utm_forward(const double* lat, const double* lon, int64_t n, int zone, int south, double* e, double* nn)
 {

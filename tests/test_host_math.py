@@ -44,6 +44,10 @@ def hh():
     L.hh_ekf_fuse.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, f64p, f64p, C.POINTER(EkfConfig), f64p, f64p]
     L.hh_umeyama.restype = C.c_int
     L.hh_umeyama.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.POINTER(C.c_double)]
+    L.hh_umeyama_polar.restype = C.c_int
+    L.hh_umeyama_polar.argtypes = [f64p, f64p, C.c_int64, f64p, f64p, C.POINTER(C.c_double)]
+    L.hh_polar_applies.restype = C.c_int
+    L.hh_polar_applies.argtypes = [f64p]
     L.hh_utm_forward.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
     L.hh_utm_inverse.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
     return L
@@ -99,6 +103,71 @@ def test_umeyama_core(hh, golden):
         np.testing.assert_allclose(R, g[f"{name}_R"], atol=1e-12, rtol=0, err_msg=str(name))
         np.testing.assert_allclose(t, g[f"{name}_t"], atol=1e-8, rtol=0, err_msg=str(name))
         assert abs(s.value - float(g[f"{name}_s"])) < 1e-12
+
+
+def test_umeyama_polar_route(hh, golden):
+    """umeyama_finalize<true> (the fused pipeline's prelude: Newton polar iteration + cofactor power iteration for the reflection
+    case) against the SVD route and the oracle: goldens (degenerate ones must fall back), track-shaped sets whose vertical
+    direction is noise (about half of them need ref :441-442), conditioning up to 1e13."""
+    g = golden("sim3_cases.npz")
+    for name in g["names"]:
+        src, dst = np.ascontiguousarray(g[f"{name}_src"]).reshape(-1, 3), np.ascontiguousarray(g[f"{name}_dst"]).reshape(-1, 3)
+        R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+        R2, t2, s2 = np.empty((3, 3)), np.empty(3), C.c_double()
+        rc = hh.hh_umeyama(src, dst, src.shape[0], R, t, C.byref(s))
+        rc2 = hh.hh_umeyama_polar(src, dst, src.shape[0], R2, t2, C.byref(s2))
+        assert rc == rc2, name
+        if rc == 1:
+            continue
+        np.testing.assert_allclose(R2, R, atol=1e-12, rtol=0, err_msg=str(name))
+        np.testing.assert_allclose(t2, t, atol=1e-8, rtol=0, err_msg=str(name))
+        assert abs(s2.value - s.value) < 1e-12 * max(1.0, abs(s.value)), name
+    rng = np.random.default_rng(3)
+    n_polar = n_refl = 0
+    for trial in range(400):
+        n = int(rng.integers(8, 400)); tt = np.linspace(0, 1, n); curv = rng.uniform(0.02, 3.0)
+        vert = 10.0 ** rng.uniform(-7, 0.5)
+        src = np.c_[np.cumsum(np.sin(curv * tt) * 1.4), vert * rng.normal(size=n), np.cumsum(np.cos(curv * tt) * 1.4)]
+        th = rng.uniform(0, 2 * np.pi)
+        Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]]) @ np.array([[1.0, 0, 0], [0, 0, -1], [0, 1, 0]])
+        dst = rng.uniform(0.5, 2.0) * src @ Rz.T + np.array([4.5e5, 5.4e6, 100.0]) + rng.normal(size=src.shape) * 0.45
+        a, b = src - src.mean(0), dst - dst.mean(0)
+        H = np.ascontiguousarray(a.T @ b)
+        n_polar += hh.hh_polar_applies(H); n_refl += np.linalg.det(H) < 0
+        R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+        R2, t2, s2 = np.empty((3, 3)), np.empty(3), C.c_double()
+        assert hh.hh_umeyama(src, dst, n, R, t, C.byref(s)) == hh.hh_umeyama_polar(src, dst, n, R2, t2, C.byref(s2))
+        Ro, to, so = orc.compute_sim3_transform(src, dst)
+        for Rx, tx, sx in ((R2, t2, s2.value),):
+            assert abs(np.linalg.det(Rx) - 1.0) < 1e-12
+            np.testing.assert_allclose(Rx, R, atol=2e-12, rtol=0)          # both routes are ~1e-13 from the exact rotation
+            np.testing.assert_allclose(Rx, Ro, atol=2e-12, rtol=0)
+            assert abs(sx - so) < 1e-12 * so
+            np.testing.assert_allclose(sx * src @ Rx.T + tx, so * src @ Ro.T + to, atol=1e-8, rtol=0)
+    assert n_polar > 300 and n_refl > 100                                   # the fast route is the one exercised, reflections included
+    # mirrored clouds with a controlled sigma3/sigma2 from 1e-8 to 0.7 (beyond 0.33 the route must hand over to the SVD, not guess)
+    took = 0
+    for trial in range(300):
+        n = 60
+        e = 10.0 ** rng.uniform(-4, -0.08)
+        src = rng.normal(size=(n, 3)) * np.array([30.0, 3.0, 3.0 * e])
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        Q = Q * np.sign(np.linalg.det(Q))
+        dst = 1.3 * (src * np.array([1.0, 1.0, -1.0])) @ Q.T + rng.normal(size=(n, 3)) * 1e-3 * e + np.array([4.5e5, 5.4e6, 100.0])
+        a, b = src - src.mean(0), dst - dst.mean(0)
+        H = np.ascontiguousarray(a.T @ b)
+        assert np.linalg.det(H) < 0
+        sv = np.linalg.svd(H, compute_uv=False)
+        ok = hh.hh_polar_applies(H); took += ok
+        if sv[2] / sv[1] < 0.25:
+            assert ok, (trial, sv)
+        R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
+        R2, t2, s2 = np.empty((3, 3)), np.empty(3), C.c_double()
+        assert hh.hh_umeyama(src, dst, n, R, t, C.byref(s)) == hh.hh_umeyama_polar(src, dst, n, R2, t2, C.byref(s2)) == 0
+        tol = 5e-13 / max(1e-3, 1.0 - sv[2] / sv[1])                       # the flipped direction is conditioned like 1 / (sigma2 - sigma3)
+        np.testing.assert_allclose(R2, R, atol=tol, rtol=0, err_msg=f"sigma3/sigma2 = {sv[2] / sv[1]:.3g}")
+        assert abs(s2.value - s.value) < 1e-12 * s.value
+    assert took > 200
 
 
 def test_utm_core(hh, golden):

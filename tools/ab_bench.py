@@ -28,7 +28,7 @@ res = []
 bt = B.TrajectoryBatch.synthetic(1000, 271, layout=0, seed=20250523)
 o = B.FusedPoses(0, 1000, 271, "cuda")
 res.append(("c2_ekf", timed(lambda: B.ekf_fuse_batch(bt, out=o), 500)))
-for duo in (0, 1, 2, -1):
+for duo in (0, 1, -1):
     try:
         ctx.set_option("duo_kernel", duo)
     except Exception:
