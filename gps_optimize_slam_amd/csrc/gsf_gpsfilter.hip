@@ -212,7 +212,6 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     __shared__ int sh_nin[CH_MAX_TRIALS];
     __shared__ double sh_score[CH_MAX_TRIALS];
     __shared__ int32_t sh_end[CH_MAX_TRIALS];
-    __shared__ int sh_res[3];
     extern __shared__ uint16_t dyn[];                                     // [jseq_elems] swap partners, then int32 idx[max_trials * ms]
     uint16_t* jseq = dyn;
     int32_t* sh_idx = (int32_t*)(dyn + ((jseq_elems + 1) & ~1));
@@ -241,17 +240,25 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             const double* yp = pos + (r_base + r0) * 3 + ax;
             for (int i = lane; i <= MT_N; i += 64) snap[i] = (i < MT_N) ? mt[i] : (uint32_t)pos_mt;
             __syncthreads();
-            mt_draw_choice(mt, pos_mt, n, max_trials, ms, jseq, jseq_elems, sh_idx, sh_end, lane);
-            for (int tau = lane; tau < max_trials; tau += 64) {
-                int c; double sc;
-                score_trial(tp, yp, 3, n, sh_idx + (size_t)tau * ms, ms, degree, thr, c, sc);
-                sh_nin[tau] = c; sh_score[tau] = sc;
-            }
-            __syncthreads();
-            if (lane == 0) {                                              // RANSACRegressor.fit's loop over the trials, in order
-                int best = -1, best_n = 1, ntr = 0;
-                double best_score = -INFINITY, max_tr = (double)max_trials;
-                while ((double)ntr < max_tr) {
+            // RANSACRegressor.fit's loop over the trials, in order, with the trials drawn and scored in growing batches (8, 16, 32, ...):
+            // the loop shortens max_trials as soon as a consensus set is found (typically to 4-15 of the 50), and every trial costs
+            // ~600 dependent instructions of the stream walk.  The walk itself runs redundantly on every lane (wave-uniform state).
+            int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0;
+            double best_score = -INFINITY, max_tr = (double)max_trials;
+            for (int tbn = 8; (double)ntr < max_tr; tbn *= 2) {
+                const int nb = (max_trials - drawn < tbn) ? (max_trials - drawn) : tbn;
+                if (nb <= 0) break;
+                mt_draw_choice(mt, pos_mt, n, nb, ms, jseq, jseq_elems, sh_idx + (size_t)drawn * ms, sh_end + drawn, lane);
+                for (int tau = lane; tau < nb; tau += 64) {
+                    int c; double sc;
+                    score_trial(tp, yp, 3, n, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, thr, c, sc);
+                    sh_nin[drawn + tau] = c; sh_score[drawn + tau] = sc;
+                    sh_end[drawn + tau] += raw_base;                          // outputs consumed since the window-axis start
+                }
+                __syncthreads();
+                drawn += nb;
+                raw_base = sh_end[drawn - 1];
+                while ((double)ntr < max_tr && ntr < drawn) {
                     const int k = ntr++;
                     const int c = sh_nin[k];
                     if (c < best_n) continue;
@@ -260,10 +267,9 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                     best = k; best_n = c; best_score = sc;
                     max_tr = fmin(max_tr, dynamic_max_trials(best_n, n, ms, stop_prob));
                 }
-                sh_res[0] = best; sh_res[1] = ntr; sh_res[2] = ntr > 0 ? sh_end[ntr - 1] : 0;
+                __syncthreads();
             }
-            __syncthreads();
-            const int best = sh_res[0], skip = sh_res[2];
+            const int skip = ntr > 0 ? sh_end[ntr - 1] : 0;
             // the stream goes back to the window-axis start and forward by what n_trials_ draws consume
             for (int i = lane; i < MT_N; i += 64) mt[i] = snap[i];
             pos_mt = (int)snap[MT_N];
