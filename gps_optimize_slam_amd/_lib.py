@@ -72,8 +72,10 @@ SIGNATURES = {
     "gsf_utm_forward": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "gsf_utm_inverse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "gsf_gps_rows_to_utm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gsf_gps_rows_to_utm_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_geodetic_to_enu_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_ransac_poly_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
+    "gsf_ransac_poly_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -86,11 +88,14 @@ SIGNATURES = {
     "gsf_mt19937_choice_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gsf_fuse_pipeline_robust_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
                                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_fuse_pipeline_robust_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
+                                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_apply_sim3_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_apply_sim3_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_ekf_fuse_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_ekf_fuse_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_fuse_pipeline_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_ekf_fuse_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_time_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),

@@ -364,4 +364,82 @@ int gsf_ekf_fuse_batch(gsf_ctx* ctx, int32_t layout, const double* ts, const dou
     ST_RUN(gsf_ekf_fuse_batch_dev(ctx, layout, dts, dpos, dquat, dgps, dval, dip, diq, cfg, B, N, dpo, dqo, dst_));
 }
 
+// steps 3-5 of main_process_gui with the plain fit, host arrays in / out (one upload, one launch, one download)
+int gsf_fuse_pipeline_batch(gsf_ctx* ctx, int32_t layout, const double* ts, const double* pos, const double* quat, const double* gps,
+                            const uint8_t* valid, const gsf_ekf_config* cfg, int64_t B, int64_t N, double* R, double* t, double* s,
+                            double* pos_out, double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(ctx && cfg && B >= 0 && N >= 0, "bad arguments");
+    if (B == 0 || N == 0) return GSF_OK;
+    GSF_REQUIRE(ts && pos && quat && gps && valid && R && t && s && pos_out && quat_out && status, "NULL array");
+    const size_t P = (size_t)B * (size_t)N;
+    ST_BEGIN(P * 145 + (size_t)B * 108, 11);
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgps = st.in(gps, P * 3); const uint8_t* dval = st.in(valid, P);
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_fuse_pipeline_batch_dev(ctx, layout, dts, dpos, dquat, dgps, dval, cfg, B, N, dR, dt, ds, dpo, dqo, dst_));
+}
+
+// the same steps with the reference's robust fit; mt_state[B][625] (host, in/out) is each trajectory's NumPy legacy generator state
+int gsf_fuse_pipeline_robust_batch(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
+                                   const uint8_t* valid, const gsf_ekf_config* cfg, int64_t B, int64_t N, int32_t min_samples,
+                                   double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t* mt_state, double* R,
+                                   double* t, double* s, double* pos_out, double* quat_out, int32_t* status, int32_t* n_inliers,
+                                   uint8_t* inlier_mask)
+{
+    GSF_REQUIRE(ctx && cfg && B >= 0 && N >= 0 && mt_state, "bad arguments");
+    if (B == 0 || N == 0) return GSF_OK;
+    GSF_REQUIRE(ts && pos && quat && gps && valid && R && t && s && pos_out && quat_out && status && n_inliers, "NULL array");
+    const size_t P = (size_t)B * (size_t)N;
+    ST_BEGIN(P * 146 + (size_t)B * (112 + 625 * 8), 15);
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgps = st.in(gps, P * 3); const uint8_t* dval = st.in(valid, P);
+    const uint32_t* dst_in = st.in(mt_state, (size_t)B * 625);
+    uint32_t* dstate = st.out(mt_state, (size_t)B * 625);
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
+    int32_t* dni = st.out(n_inliers, (size_t)B);
+    uint8_t* dmask = inlier_mask ? st.out(inlier_mask, P) : nullptr;
+    int rc = st.upload();
+    if (rc) return rc;
+    GSF_HIP(hipMemcpyAsync(dstate, dst_in, (size_t)B * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = gsf_fuse_pipeline_robust_batch_dev(ctx, dts, dpos, dquat, dgps, dval, cfg, B, N, min_samples, residual_threshold, max_trials,
+                                            min_inliers_needed, dstate, dR, dt, ds, dpo, dqo, dst_, dni, dmask);
+    if (rc) return rc;
+    return st.finish();
+}
+
+// load_gps_data's geodesy slice for B ragged logs held by the host
+int gsf_gps_rows_to_utm_batch(gsf_ctx* ctx, const double* llh, const int64_t* offsets, int64_t B, double* utm_rows, int32_t* zone, int32_t* south)
+{
+    GSF_REQUIRE(ctx && offsets && B >= 0 && zone && south, "bad arguments");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (llh && utm_rows)), "bad offsets / NULL rows");
+    ST_BEGIN((size_t)total * 48 + (size_t)(B + 1) * 8 + (size_t)B * 8, 5);
+    const double* dllh = st.in(llh, (size_t)total * 3); const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    double* dutm = st.out(utm_rows, (size_t)total * 3); int32_t* dz = st.out(zone, (size_t)B); int32_t* dso = st.out(south, (size_t)B);
+    ST_RUN(gsf_gps_rows_to_utm_batch_dev(ctx, dllh, doff, B, dutm, dz, dso));
+}
+
+// one RANSACRegressor.fit per problem with host-drawn sample sets, host arrays in / out
+int gsf_ransac_poly_batch(gsf_ctx* ctx, const double* t, const double* y, const int64_t* offsets, int64_t P, const int32_t* sample_idx,
+                          int32_t max_trials, int32_t min_samples, int32_t degree, double residual_threshold, double stop_probability,
+                          uint8_t* inlier_mask, int32_t* n_trials, int32_t* n_inliers, int32_t* status)
+{
+    GSF_REQUIRE(ctx && offsets && P >= 0 && n_trials && n_inliers && status, "bad arguments");
+    GSF_REQUIRE(max_trials >= 1 && min_samples >= 1, "bad max_trials / min_samples");
+    if (P == 0) return GSF_OK;
+    const int64_t total = offsets[P];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (t && y && inlier_mask)) && sample_idx, "bad offsets / NULL arrays");
+    const size_t nidx = (size_t)P * (size_t)max_trials * (size_t)min_samples;
+    ST_BEGIN((size_t)total * 17 + (size_t)(P + 1) * 8 + nidx * 4 + (size_t)P * 12, 8);
+    const double* dt = st.in(t, (size_t)total); const double* dy = st.in(y, (size_t)total); const int64_t* doff = st.in(offsets, (size_t)P + 1);
+    const int32_t* didx = st.in(sample_idx, nidx);
+    uint8_t* dmask = st.out(inlier_mask, (size_t)total); int32_t* dnt = st.out(n_trials, (size_t)P); int32_t* dni = st.out(n_inliers, (size_t)P);
+    int32_t* dst_ = st.out(status, (size_t)P);
+    ST_RUN(gsf_ransac_poly_batch_dev(ctx, dt, dy, doff, P, didx, max_trials, min_samples, degree, residual_threshold, stop_probability, dmask, dnt, dni, dst_));
+}
+
 }  // extern "C"

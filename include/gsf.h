@@ -126,6 +126,8 @@ GSF_API int gsf_utm_inverse(gsf_ctx *ctx, const double *easting, const double *n
    reference drops are NaN rows here (a device array cannot shrink); zone[b] = 0 for a log without a valid row. */
 GSF_API int gsf_gps_rows_to_utm_batch_dev(gsf_ctx *ctx, const double *llh, const int64_t *offsets, int64_t B, double *utm_rows, int32_t *zone,
                                           int32_t *south);
+GSF_API int gsf_gps_rows_to_utm_batch(gsf_ctx *ctx, const double *llh, const int64_t *offsets, int64_t B, double *utm_rows, int32_t *zone,
+                                      int32_t *south);                                   /* the same with host arrays */
 
 /* WGS84 geodetic -> local East-North-Up about a per-trajectory origin ref_llh[B][3] = (lat0 deg, lon0 deg, h0 m).  Offered in
    addition to UTM: the reference's pipeline projects with UTM (EKFGPSSLAM.py:266-271); BASELINE.json words the step as
@@ -145,6 +147,10 @@ GSF_API int gsf_ransac_poly_batch_dev(gsf_ctx *ctx, const double *t, const doubl
                                       const int32_t *sample_idx, int32_t max_trials, int32_t min_samples, int32_t degree,
                                       double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,
                                       int32_t *n_inliers, int32_t *status);
+GSF_API int gsf_ransac_poly_batch(gsf_ctx *ctx, const double *t, const double *y, const int64_t *offsets, int64_t P,
+                                  const int32_t *sample_idx, int32_t max_trials, int32_t min_samples, int32_t degree,
+                                  double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,
+                                  int32_t *n_inliers, int32_t *status);                  /* the same with host arrays */
 
 /* The WHOLE pre-filter of B GNSS logs as one device chain, draws included.  Log b = rows offsets[b]..offsets[b+1] of t[] and
    pos[][3] (UTM E, N, alt); its windows are rows win_rows[2w], win_rows[2w+1] (relative to the log's first row; found by the host
@@ -240,6 +246,9 @@ GSF_API int gsf_ekf_fuse_batch(gsf_ctx *ctx, int32_t layout, const double *ts, c
 GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
                                 const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
                                 double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
+GSF_API int gsf_fuse_pipeline_batch(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
+                            const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
+                            double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);   /* host arrays */
 
 /* ---- the same steps with the reference's ROBUST fit (compute_sim3_transform_robust, EKFGPSSLAM.py:1002, :389-426) ---------- */
 /* One device chain, no host round trip: rows with valid finite GNSS -> max_trials hypotheses drawn from each trajectory's
@@ -252,6 +261,12 @@ GSF_API int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx *ctx, const double *ts, c
                                                double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t *mt_state,
                                                double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status,
                                                int32_t *n_inliers, uint8_t *inlier_mask);
+/* host arrays; mt_state[B][625] in/out as in gsf_sim3_ransac_mt_batch (np.random.get_state(): key[624] + pos) */
+GSF_API int gsf_fuse_pipeline_robust_batch(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                           const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N, int32_t min_samples,
+                                           double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t *mt_state,
+                                           double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status,
+                                           int32_t *n_inliers, uint8_t *inlier_mask);
 
 /* ragged forms (trajectories of different lengths): flat [total][C] arrays, trajectory b = rows offsets[b]..offsets[b+1] */
 GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,

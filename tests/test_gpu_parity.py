@@ -1040,3 +1040,62 @@ def test_two_wave_pipeline_kernels_are_bit_identical(B):
         for key in list(modes[1:]) + ["auto"]:
             for x0, x1 in zip(res[0], res[key]):
                 np.testing.assert_array_equal(x0, x1, err_msg=f"N={N} B={nb} duo={key}")
+
+
+def test_host_pointer_forms_equal_device_forms(B):
+    """The host-array entry points added for a ctypes-only caller (fused pipeline, robust pipeline, the geodesy slice of
+    load_gps_data, the fed-sample polynomial RANSAC) stage through the context's arena and run the SAME launches as the `_dev`
+    forms: identical bits, and the generator states come back advanced identically."""
+    import ctypes as C
+    import torch
+    from gps_optimize_slam_amd import _lib
+    from gps_optimize_slam_amd.ekfgpsslam import CONFIG
+    L, ctx = _lib.load(), B.context()
+    h, hp = ctx.handle, _lib.hptr
+    cfg = _lib.EkfConfig.from_config(CONFIG)
+    nb, N = 37, 193
+    batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=5)
+    hb = batch.host_traj_major()
+    # ---- plain pipeline
+    out, R, t, s = B.fuse_pipeline_batch(batch)
+    pd, qd, sd = out.host_traj_major()
+    Rh, th, sh = np.empty((nb, 9)), np.empty((nb, 3)), np.empty(nb)
+    ph, qh, sth = np.empty((nb, N, 3)), np.empty((nb, N, 4)), np.empty(nb, dtype=np.int32)
+    _lib.check(L.gsf_fuse_pipeline_batch(h, 0, hp(hb["ts"]), hp(hb["pos"]), hp(hb["quat"]), hp(hb["gps"]), hp(hb["valid"]), C.byref(cfg), nb, N,
+                                         hp(Rh), hp(th), hp(sh), hp(ph), hp(qh), hp(sth)))
+    for a, b_ in ((ph, pd), (qh, qd), (sth, sd), (Rh, R.cpu().numpy()), (th, t.cpu().numpy()), (sh, s.cpu().numpy())):
+        np.testing.assert_array_equal(a, b_)
+    # ---- robust pipeline: per-trajectory legacy streams
+    r = CONFIG["sim3_ransac"]
+    st_dev = B.mt19937_seed(np.arange(100, 100 + nb))
+    st_host = st_dev.cpu().numpy().copy()
+    outr, Rr, tr, sr, nin, mask = B.fuse_pipeline_robust_batch(batch, st_dev)
+    pr, qr, str_ = outr.host_traj_major()
+    ninh, maskh = np.empty(nb, dtype=np.int32), np.empty((nb, N), dtype=np.uint8)
+    _lib.check(L.gsf_fuse_pipeline_robust_batch(h, hp(hb["ts"]), hp(hb["pos"]), hp(hb["quat"]), hp(hb["gps"]), hp(hb["valid"]), C.byref(cfg), nb, N,
+                                                int(r["min_samples"]), float(r["residual_threshold"]), int(r["max_trials"]), int(r["min_inliers_needed"]),
+                                                hp(st_host), hp(Rh), hp(th), hp(sh), hp(ph), hp(qh), hp(sth), hp(ninh), hp(maskh)))
+    for a, b_ in ((ph, pr), (qh, qr), (sth, str_), (Rh, Rr.cpu().numpy()), (sh, sr.cpu().numpy()), (ninh, nin.cpu().numpy()), (maskh, mask.cpu().numpy()),
+                  (st_host, st_dev.cpu().numpy())):
+        np.testing.assert_array_equal(a, b_)
+    # ---- geodesy slice of load_gps_data
+    gb = B.GeodeticBatch.synthetic(11, 150, seed=3)
+    offs = gb.gps_offsets.cpu().numpy(); llh = gb.gps_llh.cpu().numpy()
+    utm_d = torch.empty_like(gb.gps_llh); z_d = torch.empty(11, dtype=torch.int32, device="cuda"); s_d = torch.empty(11, dtype=torch.int32, device="cuda")
+    _lib.check(L.gsf_gps_rows_to_utm_batch_dev(h, B._p(gb.gps_llh), B._p(gb.gps_offsets), 11, B._p(utm_d), B._p(z_d), B._p(s_d)))
+    utm_h, z_h, s_h = np.empty_like(llh), np.empty(11, dtype=np.int32), np.empty(11, dtype=np.int32)
+    _lib.check(L.gsf_gps_rows_to_utm_batch(h, hp(llh), hp(offs), 11, hp(utm_h), hp(z_h), hp(s_h)))
+    np.testing.assert_array_equal(utm_h, utm_d.cpu().numpy()); np.testing.assert_array_equal(z_h, z_d.cpu().numpy())
+    np.testing.assert_array_equal(s_h, s_d.cpu().numpy())
+    # ---- fed-sample polynomial RANSAC
+    rng = np.random.default_rng(2)
+    P, rows, trials, ms = 9, 120, 40, 6
+    tt = np.sort(rng.uniform(0, 30, size=(P, rows)), axis=1).ravel(); yy = (0.3 * tt ** 2 - tt + rng.normal(size=tt.size) * 0.2)
+    yy[rng.integers(0, yy.size, 60)] += 25.0
+    po = np.arange(0, (P + 1) * rows, rows, dtype=np.int64)
+    idx = np.stack([np.stack([rng.permutation(rows)[:ms] for _ in range(trials)]) for _ in range(P)]).astype(np.int32)
+    m_d, ntr_d, nin_d, st_d = B.ransac_poly_batch(torch.as_tensor(tt).cuda(), torch.as_tensor(yy).cuda(), torch.as_tensor(po).cuda(), torch.as_tensor(idx).cuda(), 2, 1.0)
+    m_h, ntr_h, nin_h, st_h = np.empty(tt.size, dtype=np.uint8), np.empty(P, dtype=np.int32), np.empty(P, dtype=np.int32), np.empty(P, dtype=np.int32)
+    _lib.check(L.gsf_ransac_poly_batch(h, hp(tt), hp(yy), hp(po), P, hp(idx), trials, ms, 2, 1.0, 0.99, hp(m_h), hp(ntr_h), hp(nin_h), hp(st_h)))
+    for a, b_ in ((m_h, m_d), (ntr_h, ntr_d), (nin_h, nin_d), (st_h, st_d)):
+        np.testing.assert_array_equal(a, b_.cpu().numpy())
