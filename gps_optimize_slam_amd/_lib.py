@@ -74,12 +74,14 @@ SIGNATURES = {
     "gsf_gps_rows_to_utm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_gps_rows_to_utm_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_geodetic_to_enu_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gsf_geodetic_to_enu_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsf_ransac_poly_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "gsf_ransac_poly_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_windows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "gsf_sim3_umeyama_windows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -97,7 +99,9 @@ SIGNATURES = {
     "gsf_fuse_pipeline_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_ekf_fuse_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp]),
+    "gsf_ekf_fuse_ragged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_fuse_pipeline_ragged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_time_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
     "gsf_time_align_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "gsf_eval_errors_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _vp]),

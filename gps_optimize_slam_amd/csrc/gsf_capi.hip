@@ -410,6 +410,71 @@ int gsf_fuse_pipeline_robust_batch(gsf_ctx* ctx, const double* ts, const double*
     return st.finish();
 }
 
+// tracks of different lengths (flat [total][C] host arrays, trajectory b = rows offsets[b]..offsets[b+1])
+int gsf_ekf_fuse_ragged(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps, const uint8_t* valid,
+                        const int64_t* offsets, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                        double* pos_out, double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(ctx && cfg && offsets && B >= 0 && init_pos && init_quat && status, "bad arguments");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (ts && pos && quat && gps && valid && pos_out && quat_out)), "bad offsets / NULL arrays");
+    const size_t P = (size_t)total;
+    ST_BEGIN(P * 145 + (size_t)(B + 1) * 8 + (size_t)B * 60, 11);
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgps = st.in(gps, P * 3); const uint8_t* dval = st.in(valid, P); const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    const double* dip = st.in(init_pos, (size_t)B * 3); const double* diq = st.in(init_quat, (size_t)B * 4);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_ekf_fuse_ragged_dev(ctx, dts, dpos, dquat, dgps, dval, doff, dip, diq, cfg, B, dpo, dqo, dst_));
+}
+int gsf_fuse_pipeline_ragged(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps, const uint8_t* valid,
+                             const int64_t* offsets, const gsf_ekf_config* cfg, int64_t B, double* R, double* t, double* s, double* pos_out,
+                             double* quat_out, int32_t* status)
+{
+    GSF_REQUIRE(ctx && cfg && offsets && B >= 0 && R && t && s && status, "bad arguments");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (ts && pos && quat && gps && valid && pos_out && quat_out)), "bad offsets / NULL arrays");
+    const size_t P = (size_t)total;
+    ST_BEGIN(P * 145 + (size_t)(B + 1) * 8 + (size_t)B * 108, 12);
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgps = st.in(gps, P * 3); const uint8_t* dval = st.in(valid, P); const int64_t* doff = st.in(offsets, (size_t)B + 1);
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_fuse_pipeline_ragged_dev(ctx, dts, dpos, dquat, dgps, dval, doff, cfg, B, dR, dt, ds, dpo, dqo, dst_));
+}
+
+// B equal-size windows of W point pairs (sliding-window re-alignment) held by the host
+int gsf_sim3_umeyama_windows(gsf_ctx* ctx, const double* src, const double* dst, const uint8_t* mask, int64_t B, int32_t W, double* R, double* t,
+                             double* s, int32_t* status)
+{
+    GSF_REQUIRE(ctx && B >= 0 && W >= 0 && R && t && s && status, "bad arguments");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(W == 0 || (src && dst), "NULL points");
+    const size_t P = (size_t)B * (size_t)W;
+    ST_BEGIN(P * 49 + (size_t)B * 108, 7);
+    const double* dsrc = st.in(src, P * 3); const double* ddst = st.in(dst, P * 3);
+    const uint8_t* dmask = mask ? st.in(mask, P) : nullptr;
+    double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B); int32_t* dst_ = st.out(status, (size_t)B);
+    ST_RUN(gsf_sim3_umeyama_windows_dev(ctx, dsrc, ddst, dmask, B, W, dR, dt, ds, dst_));
+}
+
+// WGS84 -> local ENU about per-trajectory origins, host arrays
+int gsf_geodetic_to_enu_batch(gsf_ctx* ctx, const double* lat_deg, const double* lon_deg, const double* alt, const int64_t* offsets,
+                              const double* ref_llh, int64_t B, double* east, double* north, double* up)
+{
+    GSF_REQUIRE(ctx && offsets && ref_llh && B >= 0, "bad arguments");
+    if (B == 0) return GSF_OK;
+    const int64_t total = offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (lat_deg && lon_deg && alt && east && north && up)), "bad offsets / NULL arrays");
+    const size_t P = (size_t)total;
+    ST_BEGIN(P * 48 + (size_t)(B + 1) * 8 + (size_t)B * 24, 8);
+    const double* dla = st.in(lat_deg, P); const double* dlo = st.in(lon_deg, P); const double* dal = st.in(alt, P);
+    const int64_t* doff = st.in(offsets, (size_t)B + 1); const double* dref = st.in(ref_llh, (size_t)B * 3);
+    double* de = st.out(east, P); double* dn = st.out(north, P); double* du = st.out(up, P);
+    ST_RUN(gsf_geodetic_to_enu_batch_dev(ctx, dla, dlo, dal, doff, dref, B, de, dn, du));
+}
+
 // load_gps_data's geodesy slice for B ragged logs held by the host
 int gsf_gps_rows_to_utm_batch(gsf_ctx* ctx, const double* llh, const int64_t* offsets, int64_t B, double* utm_rows, int32_t* zone, int32_t* south)
 {

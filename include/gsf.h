@@ -134,6 +134,8 @@ GSF_API int gsf_gps_rows_to_utm_batch(gsf_ctx *ctx, const double *llh, const int
    "WGS84 -> local ENU". */
 GSF_API int gsf_geodetic_to_enu_batch_dev(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const double *alt, const int64_t *offsets,
                                           const double *ref_llh, int64_t B, double *east, double *north, double *up);
+GSF_API int gsf_geodetic_to_enu_batch(gsf_ctx *ctx, const double *lat_deg, const double *lon_deg, const double *alt, const int64_t *offsets,
+                                      const double *ref_llh, int64_t B, double *east, double *north, double *up);   /* host arrays */
 
 /* ---- next-3: GPS outlier pre-filter (filter_gps_outliers_ransac, EKFGPSSLAM.py:136-247) ------------------------------------
    One problem = one RANSACRegressor.fit of the reference (one window x one coordinate axis): rows offsets[p]..offsets[p+1] of
@@ -182,6 +184,8 @@ GSF_API int gsf_sim3_umeyama_batch_dev(gsf_ctx *ctx, const double *src, const do
    moments pass and the per-window 3x3 SVD run as two launches (a 192-byte record per window in the context's workspace). */
 GSF_API int gsf_sim3_umeyama_windows_dev(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask, int64_t B, int32_t W,
                                          double *R, double *t, double *s, int32_t *status);
+GSF_API int gsf_sim3_umeyama_windows(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask, int64_t B, int32_t W,
+                                     double *R, double *t, double *s, int32_t *status);               /* host arrays */
 GSF_API int gsf_sim3_umeyama_batch(gsf_ctx *ctx, const double *src, const double *dst, const uint8_t *mask,
                            const int64_t *offsets, int64_t B, double *R, double *t, double *s, int32_t *status);
 
@@ -275,6 +279,13 @@ GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double
 GSF_API int gsf_fuse_pipeline_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
                                          const uint8_t *valid, const int64_t *offsets, const gsf_ekf_config *cfg, int64_t B, double *R,
                                          double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
+/* the same with host arrays */
+GSF_API int gsf_ekf_fuse_ragged(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                const uint8_t *valid, const int64_t *offsets, const double *init_pos, const double *init_quat,
+                                const gsf_ekf_config *cfg, int64_t B, double *pos_out, double *quat_out, int32_t *status);
+GSF_API int gsf_fuse_pipeline_ragged(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                     const uint8_t *valid, const int64_t *offsets, const gsf_ekf_config *cfg, int64_t B, double *R,
+                                     double *t, double *s, double *pos_out, double *quat_out, int32_t *status);
 
 /* ---- time alignment (dynamic_time_alignment, EKFGPSSLAM.py:325-387) ------------------------------ */
 /* B trajectories: SLAM stamps slam_t[slam_offsets[b]..), GNSS fixes gps_t / gps_p[.][3] at gps_offsets (any order, duplicates

@@ -1099,3 +1099,38 @@ def test_host_pointer_forms_equal_device_forms(B):
     _lib.check(L.gsf_ransac_poly_batch(h, hp(tt), hp(yy), hp(po), P, hp(idx), trials, ms, 2, 1.0, 0.99, hp(m_h), hp(ntr_h), hp(nin_h), hp(st_h)))
     for a, b_ in ((m_h, m_d), (ntr_h, ntr_d), (nin_h, nin_d), (st_h, st_d)):
         np.testing.assert_array_equal(a, b_.cpu().numpy())
+    # ---- ragged tracks (different lengths), the equal-window Umeyama and the ENU projection
+    lens = np.array([3, 64, 65, 190, 1, 128, 77], dtype=np.int64)
+    ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pick = np.concatenate([np.arange(k * N, k * N + lens[k]) for k in range(len(lens))])
+    fl = {k: np.ascontiguousarray(hb[k].reshape((nb * N,) + hb[k].shape[2:])[pick]) for k in ("ts", "pos", "quat", "gps", "valid")}
+    nr, T = len(lens), int(ro[-1])
+    dv = {k: torch.as_tensor(v).cuda() for k, v in fl.items()}
+    dro = torch.as_tensor(ro).cuda()
+    po_d, qo_d, st_d2, R_d, t_d, s_d2 = B.fuse_pipeline_ragged(dv["ts"], dv["pos"], dv["quat"], dv["gps"], dv["valid"], dro)
+    Rr_, tr_, sr_ = np.empty((nr, 9)), np.empty((nr, 3)), np.empty(nr)
+    pr_, qr_, sx_ = np.empty((T, 3)), np.empty((T, 4)), np.empty(nr, dtype=np.int32)
+    _lib.check(L.gsf_fuse_pipeline_ragged(h, hp(fl["ts"]), hp(fl["pos"]), hp(fl["quat"]), hp(fl["gps"]), hp(fl["valid"]), hp(ro), C.byref(cfg), nr,
+                                          hp(Rr_), hp(tr_), hp(sr_), hp(pr_), hp(qr_), hp(sx_)))
+    for a, b_ in ((pr_, po_d), (qr_, qo_d), (sx_, st_d2), (Rr_, R_d), (tr_, t_d), (sr_, s_d2)):
+        np.testing.assert_array_equal(a, b_.cpu().numpy())
+    ip, iq = np.ascontiguousarray(hb["init_pos"][:nr]), np.ascontiguousarray(hb["init_quat"][:nr])
+    po_d, qo_d, st_d2 = B.ekf_fuse_ragged(dv["ts"], dv["pos"], dv["quat"], dv["gps"], dv["valid"], dro, torch.as_tensor(ip).cuda(), torch.as_tensor(iq).cuda())
+    _lib.check(L.gsf_ekf_fuse_ragged(h, hp(fl["ts"]), hp(fl["pos"]), hp(fl["quat"]), hp(fl["gps"]), hp(fl["valid"]), hp(ro), hp(ip), hp(iq), C.byref(cfg), nr,
+                                     hp(pr_), hp(qr_), hp(sx_)))
+    for a, b_ in ((pr_, po_d), (qr_, qo_d), (sx_, st_d2)):
+        np.testing.assert_array_equal(a, b_.cpu().numpy())
+    W = 50
+    sw = np.ascontiguousarray(hb["pos"][:, :W]); dw = np.ascontiguousarray(np.nan_to_num(hb["gps"][:, :W]))
+    Rw, tw, sw_, stw = B.sim3_umeyama_batch(torch.as_tensor(sw).cuda(), torch.as_tensor(dw).cuda())
+    Rwh, twh, swh, stwh = np.empty((nb, 9)), np.empty((nb, 3)), np.empty(nb), np.empty(nb, dtype=np.int32)
+    _lib.check(L.gsf_sim3_umeyama_windows(h, hp(sw), hp(dw), None, nb, W, hp(Rwh), hp(twh), hp(swh), hp(stwh)))
+    for a, b_ in ((Rwh, Rw), (twh, tw), (swh, sw_), (stwh, stw)):
+        np.testing.assert_array_equal(a, b_.cpu().numpy())
+    lat, lon, alt = (np.ascontiguousarray(llh[:, k]) for k in range(3))
+    ref = np.ascontiguousarray(np.stack([llh[offs[:-1]][:, 0], llh[offs[:-1]][:, 1], llh[offs[:-1]][:, 2]], axis=1))
+    e_d, n_d, u_d = B.geodetic_to_enu_batch(torch.as_tensor(lat).cuda(), torch.as_tensor(lon).cuda(), torch.as_tensor(alt).cuda(), gb.gps_offsets, torch.as_tensor(ref).cuda())
+    e_h, n_h, u_h = np.empty_like(lat), np.empty_like(lat), np.empty_like(lat)
+    _lib.check(L.gsf_geodetic_to_enu_batch(h, hp(lat), hp(lon), hp(alt), hp(offs), hp(ref), 11, hp(e_h), hp(n_h), hp(u_h)))
+    for a, b_ in ((e_h, e_d), (n_h, n_d), (u_h, u_d)):
+        np.testing.assert_array_equal(a, b_.cpu().numpy())
