@@ -81,7 +81,7 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     const EkfConfig k = to_core(cfg);
     // small batches of the fused pipeline: two waves per trajectory (see ekf_wave_duo_kernel).  Bit-identical to the one-wave
     // kernel, so choosing by batch size does not break shard invariance.  gsf_set_option "duo_kernel": -1 automatic, 0 never, 1 always.
-    // Measured with the polar-iteration fit (pipeline, N = 271; tools/scratch-style sweep in DESIGN 5): 15.5 vs 17.8 us at 256 tracks,
+    // Measured with the polar-iteration fit (pipeline, N = 271; tools/duo_sweep.py): 15.5 vs 17.8 us at 256 tracks,
     // 19.4 vs 18.9 us at 512, 20.9 vs 19.5 us at 1 000 (every SIMD then holds a main wave and the helper only competes with it)
     // -- automatic = up to 256 tracks.  The four-trajectory-per-block form of round 2 (main and helper of a trajectory forced onto
     // one SIMD) lost its edge with the shorter fit (20.2 vs 19.5 us at 1 000) and lives in tools/experiments/ now.
