@@ -22,10 +22,11 @@ using namespace gsf;
 
 namespace {
 
-template <bool PIPELINE, bool SMALLBATCH>
+// AXMODE 1: x and y share (P0, Q, R), z does not (checked by the launcher; the default CONFIG) -- see wave_serial_chunks
+template <bool PIPELINE, bool SMALLBATCH, int AXMODE>
 __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
-    wave_serial_body<PIPELINE, false, SMALLBATCH>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
+    wave_serial_body<PIPELINE, false, SMALLBATCH, 1, AXMODE>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 #ifndef GSF_DUO_ROLE_SHIFT
 #define GSF_DUO_ROLE_SHIFT 2        // measured best of 0..3 at 1 000 tracks (22.6 vs 23.1-23.2 us; 23.6 us without the helper)
 #endif
-template <bool PIPELINE>
+template <bool PIPELINE, int AXMODE>
 __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig cfg, int pv_stride)
 {
     extern __shared__ double gsf_pv[];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig
         __syncthreads();
         return;
     }
-    wave_serial_body<PIPELINE, true, true>(a, cfg, b, lane, gsf_pv, pv_stride);
+    wave_serial_body<PIPELINE, true, true, 1, AXMODE>(a, cfg, b, lane, gsf_pv, pv_stride);
 }
 
 EkfConfig to_core(const gsf_ekf_config* c)
@@ -79,6 +80,9 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
+    // x and y share their (P0, Q, R) and z does not (the default CONFIG): the build with that choice of scans compiled in
+    const bool xy = k.P0[1] == k.P0[0] && k.Qps[1] == k.Qps[0] && k.Rm[1] == k.Rm[0] &&
+                    !(k.P0[2] == k.P0[0] && k.Qps[2] == k.Qps[0] && k.Rm[2] == k.Rm[0]);
     // small batches of the fused pipeline: two waves per trajectory (see ekf_wave_duo_kernel).  Bit-identical to the one-wave
     // kernel, so choosing by batch size does not break shard invariance.  gsf_set_option "duo_kernel": -1 automatic, 0 never, 1 always.
     // Measured with the polar-iteration fit (pipeline, N = 271; tools/duo_sweep.py): 15.5 vs 17.8 us at 256 tracks,
@@ -87,17 +91,20 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     // one SIMD) lost its edge with the shorter fit (20.2 vs 19.5 us at 1 000) and lives in tools/experiments/ now.
     if (pipeline && !offsets && ctx->duo_kernel != 0 && N > 64 && N <= 640 && (ctx->duo_kernel == 1 || (ctx->duo_kernel == -1 && B <= 256))) {
         const int stride = (int)((N + 1) & ~(int64_t)1);
-        hipLaunchKernelGGL(ekf_wave_duo_kernel<true>, dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
+        if (xy) hipLaunchKernelGGL((ekf_wave_duo_kernel<true, 1>), dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
+        else hipLaunchKernelGGL((ekf_wave_duo_kernel<true, 0>), dim3((unsigned)B), dim3(128), (size_t)stride * 9 * sizeof(double), ctx->stream, a, k, stride);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
     }
     {
         // up to 2 048 waves (two per SIMD) the build with inlined cold blocks costs no occupancy; same arithmetic, same bits
         const bool small = B <= 2048;
-        if (pipeline) { if (small) hipLaunchKernelGGL((ekf_wave_kernel<true, true>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-                        else hipLaunchKernelGGL((ekf_wave_kernel<true, false>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); }
-        else { if (small) hipLaunchKernelGGL((ekf_wave_kernel<false, true>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k);
-               else hipLaunchKernelGGL((ekf_wave_kernel<false, false>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k); }
+#define GSF_LAUNCH_WAVE(P_, S_, X_) hipLaunchKernelGGL((ekf_wave_kernel<P_, S_, X_>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k)
+        if (pipeline) { if (small) { if (xy) GSF_LAUNCH_WAVE(true, true, 1); else GSF_LAUNCH_WAVE(true, true, 0); }
+                        else { if (xy) GSF_LAUNCH_WAVE(true, false, 1); else GSF_LAUNCH_WAVE(true, false, 0); } }
+        else { if (small) { if (xy) GSF_LAUNCH_WAVE(false, true, 1); else GSF_LAUNCH_WAVE(false, true, 0); }
+               else { if (xy) GSF_LAUNCH_WAVE(false, false, 1); else GSF_LAUNCH_WAVE(false, false, 0); } }
+#undef GSF_LAUNCH_WAVE
     }
     GSF_HIP(hipGetLastError());
     return GSF_OK;

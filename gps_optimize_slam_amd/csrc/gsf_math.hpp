@@ -283,44 +283,27 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
     double nc2 = sumsq9(C);
     if (!(det * det > 1e-28 * nc2)) return false;                          // sigma3 < 1e-14 sigma1 (also rank <= 1, NaN)
     const bool reflect = det < 0.0;
-    double v[3] = { 0.0, 0.0, 0.0 };
-    if (reflect) {                                                         // wave-uniform in the pipeline
-        const double e0 = fabs(det);                                       // e0 / nc2 >= sigma3 / sigma2  (|X0|_F = 1: sigma1 <= 1)
-        if (!(e0 < 0.3 * nc2)) return false;                               // e / (1 + e^2) < 0.3: e < 0.33, e^64 < 1e-30
-        if (e0 < 3e-3 * nc2) {
-            // well separated (the usual case): the largest row of cof, three steps of x <- cof^T (cof x)  (e^7 < 1e-17)
-            const double r0 = C[0] * C[0] + C[1] * C[1] + C[2] * C[2], r1 = C[3] * C[3] + C[4] * C[4] + C[5] * C[5],
-                         r2 = C[6] * C[6] + C[7] * C[7] + C[8] * C[8];
-            const bool p1 = r1 > r0 && r1 >= r2, p2 = r2 > r0 && r2 > r1;
-            v[0] = p2 ? C[6] : (p1 ? C[3] : C[0]); v[1] = p2 ? C[7] : (p1 ? C[4] : C[1]); v[2] = p2 ? C[8] : (p1 ? C[5] : C[2]);
+    const double e0 = fabs(det), nc20 = nc2;                               // e0 / nc20 >= sigma3 / sigma2  (|X0|_F = 1: sigma1 <= 1)
+    if (reflect && !(e0 < 0.3 * nc20)) return false;                       // e / (1 + e^2) < 0.3: e < 0.33, e^64 < 1e-30
+    // The well-separated reflection direction (the usual case): the largest row of cof(X0), three steps of x <- cof^T (cof x)
+    // (e^7 < 1e-17 for e < 3e-3).  Computed unconditionally and in the same straight-line code as the Newton steps below: it depends on
+    // cof(X0) only, and the Newton steps are a dependent chain that leaves issue slots free (a lone wave issues a dependent FP64
+    // instruction every ~6 cycles, independent ones every ~4.5).  Not normalised yet.
+    double C0[9];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double w0 = C[0] * v[0] + C[1] * v[1] + C[2] * v[2], w1 = C[3] * v[0] + C[4] * v[1] + C[5] * v[2],
-                             w2 = C[6] * v[0] + C[7] * v[1] + C[8] * v[2];
-                v[0] = C[0] * w0 + C[3] * w1 + C[6] * w2; v[1] = C[1] * w0 + C[4] * w1 + C[7] * w2; v[2] = C[2] * w0 + C[5] * w1 + C[8] * w2;
-            }
-        } else {
-            // weakly separated (e up to 0.33): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
-            // that v3 v3^T dominates by e^64; v3 is its largest column
-            double b00 = C[0] * C[0] + C[3] * C[3] + C[6] * C[6], b01 = C[0] * C[1] + C[3] * C[4] + C[6] * C[7],
-                   b02 = C[0] * C[2] + C[3] * C[5] + C[6] * C[8], b11 = C[1] * C[1] + C[4] * C[4] + C[7] * C[7],
-                   b12 = C[1] * C[2] + C[4] * C[5] + C[7] * C[8], b22 = C[2] * C[2] + C[5] * C[5] + C[8] * C[8];
+    for (int i = 0; i < 9; ++i) C0[i] = C[i];
+    double v[3];
+    {
+        const double r0 = C0[0] * C0[0] + C0[1] * C0[1] + C0[2] * C0[2], r1 = C0[3] * C0[3] + C0[4] * C0[4] + C0[5] * C0[5],
+                     r2 = C0[6] * C0[6] + C0[7] * C0[7] + C0[8] * C0[8];
+        const bool p1 = r1 > r0 && r1 >= r2, p2 = r2 > r0 && r2 > r1;
+        v[0] = p2 ? C0[6] : (p1 ? C0[3] : C0[0]); v[1] = p2 ? C0[7] : (p1 ? C0[4] : C0[1]); v[2] = p2 ? C0[8] : (p1 ? C0[5] : C0[2]);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const double rt = seed_rcp(b00 + b11 + b22);
-                b00 *= rt; b01 *= rt; b02 *= rt; b11 *= rt; b12 *= rt; b22 *= rt;
-                const double c00 = b00 * b00 + b01 * b01 + b02 * b02, c01 = b00 * b01 + b01 * b11 + b02 * b12,
-                             c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12,
-                             c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
-                b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
-            }
-            const bool p1 = b11 > b00 && b11 >= b22, p2 = b22 > b00 && b22 > b11;   // the largest diagonal entry names the largest column
-            v[0] = p2 ? b02 : (p1 ? b01 : b00); v[1] = p2 ? b12 : (p1 ? b11 : b01); v[2] = p2 ? b22 : (p1 ? b12 : b02);
+        for (int k = 0; k < 3; ++k) {
+            const double w0 = C0[0] * v[0] + C0[1] * v[1] + C0[2] * v[2], w1 = C0[3] * v[0] + C0[4] * v[1] + C0[5] * v[2],
+                         w2 = C0[6] * v[0] + C0[7] * v[1] + C0[8] * v[2];
+            v[0] = C0[0] * w0 + C0[3] * w1 + C0[6] * w2; v[1] = C0[1] * w0 + C0[4] * w1 + C0[7] * w2; v[2] = C0[2] * w0 + C0[5] * w1 + C0[8] * w2;
         }
-        const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-        if (!(vn2 > 1e-290)) return false;
-        const double rv = fast_rsqrt(vn2);
-        v[0] *= rv; v[1] *= rv; v[2] *= rv;
     }
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
@@ -348,6 +331,28 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
 #pragma unroll
             for (int c = 0; c < 3; ++c) R[r * 3 + c] = X[c * 3 + r];
     } else {
+        if (!(e0 < 3e-3 * nc20)) {
+            // weakly separated (e up to 0.33): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
+            // that v3 v3^T dominates by e^64; v3 is its largest column
+            double b00 = C0[0] * C0[0] + C0[3] * C0[3] + C0[6] * C0[6], b01 = C0[0] * C0[1] + C0[3] * C0[4] + C0[6] * C0[7],
+                   b02 = C0[0] * C0[2] + C0[3] * C0[5] + C0[6] * C0[8], b11 = C0[1] * C0[1] + C0[4] * C0[4] + C0[7] * C0[7],
+                   b12 = C0[1] * C0[2] + C0[4] * C0[5] + C0[7] * C0[8], b22 = C0[2] * C0[2] + C0[5] * C0[5] + C0[8] * C0[8];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double rt = seed_rcp(b00 + b11 + b22);
+                b00 *= rt; b01 *= rt; b02 *= rt; b11 *= rt; b12 *= rt; b22 *= rt;
+                const double c00 = b00 * b00 + b01 * b01 + b02 * b02, c01 = b00 * b01 + b01 * b11 + b02 * b12,
+                             c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12,
+                             c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
+                b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
+            }
+            const bool p1 = b11 > b00 && b11 >= b22, p2 = b22 > b00 && b22 > b11;   // the largest diagonal entry names the largest column
+            v[0] = p2 ? b02 : (p1 ? b01 : b00); v[1] = p2 ? b12 : (p1 ? b11 : b01); v[2] = p2 ? b22 : (p1 ? b12 : b02);
+        }
+        const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        if (!(vn2 > 1e-290)) return false;
+        const double rv = fast_rsqrt(vn2);
+        v[0] *= rv; v[1] *= rv; v[2] *= rv;
         const double w0 = X[0] * v[0] + X[1] * v[1] + X[2] * v[2], w1 = X[3] * v[0] + X[4] * v[1] + X[5] * v[2],
                      w2 = X[6] * v[0] + X[7] * v[1] + X[8] * v[2];                  // Q v3 (= u3)
         const double w[3] = { w0, w1, w2 };

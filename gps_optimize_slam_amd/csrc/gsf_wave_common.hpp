@@ -454,7 +454,10 @@ template <> struct RingStore<0> {
 
 // The chunk loop of the wave-per-trajectory filter, entered with the initial pose (p0, q0) and the first 64 poses already requested
 // (nxt).  Split from the prelude so that a kernel with its own fit / initial-pose logic can fall back to it (gsf_ekf_lat.hip).
-template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1>
+// AXMODE 1: the caller has checked on the host that axes x and y share (P0, Q, R) and z does not -- the default CONFIG -- so the
+// choice of scans is compiled in and the variance scans, the orientation and the x/y and z position scans sit in straight-line
+// code that the scheduler can interleave (a lone wave issues dependent FP64 / DPP work every 6-7 cycles, independent work every 4.5).
+template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1, int AXMODE = 0>
 __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane, const int64_t base,
                                                    const int64_t N, const Vec3& p0, const Quat& q0, const int32_t fit, ChunkIn nxt,
                                                    const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0,
@@ -477,9 +480,12 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
     bool c_seg_sharp = false;
     double cPos[3] = { cP[0], cP[1], cP[2] };                            // P_f at the first pose of the open outage
     int same_axis[3] = { -1, -1, -1 };                                   // wave-uniform: axis c repeats axis same_axis[c]
-    if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
-    if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
-    else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
+    if (AXMODE == 1) { same_axis[1] = 0; }                               // known at compile time (see above)
+    else {
+        if (cfg.P0[1] == cfg.P0[0] && cfg.Qps[1] == cfg.Qps[0] && cfg.Rm[1] == cfg.Rm[0]) same_axis[1] = 0;
+        if (cfg.P0[2] == cfg.P0[0] && cfg.Qps[2] == cfg.Qps[0] && cfg.Rm[2] == cfg.Rm[0]) same_axis[2] = 0;
+        else if (cfg.P0[2] == cfg.P0[1] && cfg.Qps[2] == cfg.Qps[1] && cfg.Rm[2] == cfg.Rm[1]) same_axis[2] = 1;
+    }
 
     chunk_arrived(nxt);
     GSF_STAMP(7);
@@ -505,7 +511,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         // ---- this chunk's poses were loaded one iteration ago; issue the loads of the NEXT 64 poses now so that their
         // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
         const ChunkIn in = nxt;
-        if (c0 + 64 < N) nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);
+        nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);   // unconditional (clamped to the last row past the end): no branch between the loads and the arithmetic below
         const double t = in.t;
         const Vec3 p = in.p; const Quat q = in.q; const Vec3 z = in.z;
         const bool vraw = in.v != 0;
@@ -577,30 +583,16 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         double wgt = 1.0;
         if (sharp && cfg.sharp_turn_steps > 1) wgt = 1.0 / (double)cfg.sharp_turn_steps;
 
-        // ---- orientation (ref :708-709) and predicted displacement (ref :707)
-        Quat qi; Vec3 u;
-        if (telescope) {
-            // normalize_quaternion (ref :697-700) is the identity here up to rounding: Cq and r are unit quaternions (every
-            // quaternion of the chunk passed quat_unit), so |Cq r| = 1 +- 2e-16 and its "norm > 1e-9" guard cannot fire.  The
-            // product is written out as it is.
-            qi = quat_mul(Cq, r);
-            if (c0 == 0) {                                               // wave-uniform: pose 0 keeps the initial state (ref :842)
-                qi.x = is_init ? cq0.x : qi.x; qi.y = is_init ? cq0.y : qi.y; qi.z = is_init ? cq0.z : qi.z; qi.w = is_init ? cq0.w : qi.w;
-            }
-            cq_fresh = false;
-            u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
-            u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
-        } else {
-            // inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
-            Quat D = dq;
-            const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
-#define GSF_QSTAGE(CTRL, RM) { const Quat o = dpp<CTRL, RM>(QID, D); D = quat_mul(o, D); }
-            GSF_SCAN_STAGES(GSF_QSTAGE)
-#undef GSF_QSTAGE
-            qi = ekf_normalize(quat_mul(cq, D));                         // one normalisation per chunk
-            const Quat q_prev = prev_lane(cq, qi);
-            u = quat_rotate(q_prev, dpl);
-        }
+        // ---- orientation (ref :708-709) and predicted displacement (ref :707), telescoped form -- computed unconditionally, in the same
+        // straight-line code as the variance scans below (independent work for the scheduler); a chunk that has to take the generic
+        // path overwrites both afterwards.
+        // normalize_quaternion (ref :697-700) is the identity here up to rounding: Cq and r are unit quaternions (every quaternion of
+        // the chunk passed quat_unit), so |Cq r| = 1 +- 2e-16 and its "norm > 1e-9" guard cannot fire.  The product is written out as
+        // it is; pose 0 keeps the initial state (ref :842).
+        Quat qi = quat_mul(Cq, r);
+        qi.x = is_init ? cq0.x : qi.x; qi.y = is_init ? cq0.y : qi.y; qi.z = is_init ? cq0.z : qi.z; qi.w = is_init ? cq0.w : qi.w;
+        Vec3 u = quat_rotate(Cq, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
+        u.x = stepping ? u.x : 0.0; u.y = stepping ? u.y : 0.0; u.z = stepping ? u.z : 0.0;
 
         // ---- variances (ref :712-713, :723-731): scanned here, or -- PREVAR -- already computed by the helper wave (LDS)
         double Pf[3], Pm[3], kg[3];
@@ -612,6 +604,19 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
             AxisVar v0, v1, v2;
             variance_chunk(cfg, same_axis[1], same_axis[2], dt, stepping, avail, cP[0], cP[1], cP[2], v0, v1, v2);
             Pf[0] = v0.Pf; Pf[1] = v1.Pf; Pf[2] = v2.Pf; Pm[0] = v0.Pm; Pm[1] = v1.Pm; Pm[2] = v2.Pm; kg[0] = v0.kg; kg[1] = v1.kg; kg[2] = v2.kg;
+        }
+
+        if (telescope) cq_fresh = false;
+        else {
+            // inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
+            Quat D = dq;
+            const Quat QID{ 0.0, 0.0, 0.0, 1.0 };
+#define GSF_QSTAGE(CTRL, RM) { const Quat o = dpp<CTRL, RM>(QID, D); D = quat_mul(o, D); }
+            GSF_SCAN_STAGES(GSF_QSTAGE)
+#undef GSF_QSTAGE
+            qi = ekf_normalize(quat_mul(cq, D));                         // one normalisation per chunk
+            const Quat q_prev = prev_lane(cq, qi);
+            u = quat_rotate(q_prev, dpl);
         }
 
         // ---- positions: prefix composition of affine maps x -> al x + be in chunk-local coordinates (x = p - p_carry)
@@ -741,7 +746,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
     if (lane == 0 && GSF_STATUS_PTR(a)) a.status[b] = (status | (c_prev_avail ? 0 : ST_ENDED_IN_OUTAGE)) | (PIPELINE ? (fit << 8) : 0);
 }
 
-template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1>
+template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1, int AXMODE = 0>
 __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane,
                                                  const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0)
 {
@@ -765,7 +770,7 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     GSF_STAMP(6);
     if (PREVAR) __syncthreads();                                         // the helper wave has written every chunk's variances
 
-    wave_serial_chunks<PIPELINE, PREVAR, SMALLBATCH, RINGS>(a, cfg, b, lane, base, N, p0, q0, fit, nxt, pv, pv_stride, ring_slot);
+    wave_serial_chunks<PIPELINE, PREVAR, SMALLBATCH, RINGS, AXMODE>(a, cfg, b, lane, base, N, p0, q0, fit, nxt, pv, pv_stride, ring_slot);
 }
 
 
