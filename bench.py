@@ -400,7 +400,7 @@ def worker(args):
                                   "layout": "trajectory-major AoS (wave-per-trajectory scans)", "step": "one pass over the shard: per chunk fused pipeline"
                                   + (" + all-gather of the chunk's poses (second stream, overlapped)" if world > 1 else ""),
                                   "parallelism": f"trajectory-sharded x{world}" + (" (gloo rehearsal on shared GPUs)" if rehearsal else "")},
-                          roofline={"bound": "hbm", "kernel": "ekf_wave_kernel<true, false>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          roofline={"bound": "hbm", "kernel": "ekf_wave_kernel<true, false, 1>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": co["hbm_frac"], "traffic": None, "traffic_note": "no PMC pass at this size", "alg_bytes_per_launch": info["chunk_trajectories"] * N * ALG_BYTES_PER_POSE,
                                     "kernel_ms": co["ms"] / info["chunks"]},
                           c5=info)
@@ -461,9 +461,10 @@ def worker(args):
     # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
     pipe = args.kernel == "pipeline"
     if pipe and 64 < N <= 640 and Bn <= 256:
-        kernel_name, grid_threads = "ekf_wave_duo_kernel<true>", Bn * 128                     # a helper wave per trajectory
+        kernel_name, grid_threads = "ekf_wave_duo_kernel<true, 1>", Bn * 128                     # a helper wave per trajectory
     else:
-        kernel_name, grid_threads = "ekf_wave_kernel<%s, %s>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
+        # <PIPELINE, SMALLBATCH, AXMODE>: AXMODE 1 = x and y share their noise figures, z does not (the default CONFIG, compiled-in scans)
+        kernel_name, grid_threads = "ekf_wave_kernel<%s, %s, 1>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
     traffic, traffic_src = profiled_traffic(args.workload, kernel_name, grid_threads)
     result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
                   config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)",

@@ -531,17 +531,8 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         // so the orientation needs no scan and the predicted displacement is ONE rotation by the wave-uniform Cq
         // (identical up to rounding: r conj(r) = 1 to 1 ulp for unit r).  Any invalid quaternion -> generic path below.
         const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
-        Vec3 dpl{ 0.0, 0.0, 0.0 }; Quat dq{ 0.0, 0.0, 0.0, 1.0 };
-        if (!telescope) {                                                // calculate_relative_pose, ref :77-92
-            if (!cq_fresh) { cq = quat_mul(Cq, c_r); cq_fresh = true; }  // the state quaternion the telescoped chunks did not carry
-            const Quat r1i = quat_conj(prev_lane(c_r, r));
-            dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
-            dq = quat_mul(r1i, r);
-            const bool move = stepping && both_ok;
-            dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
-            dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
-            if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
-        }
+        // (the generic path -- calculate_relative_pose per pose + a quaternion prefix product -- sits in ONE block further down, so
+        // that the usual chunk runs from the loads to the scans without a branch)
         // ---- GNSS gate (ref :867-869) and the outage structure of the chunk as ballots
         const bool avail = stepping && vraw && !(isnan(z.x) || isnan(z.y) || isnan(z.z));
         const bool av = is_init ? vraw : avail;                          // "gnss available" flag of pose i (pose 0: raw mask, :848)
@@ -551,7 +542,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         const bool recovers = stepping && av && !ap;                     // ref :879
         const bool outpair = stepping && !av && !ap;                     // poses i-1 and i both inside the outage
         const u64 start_mask = __ballot(starts), rec_mask = __ballot(recovers), pair_mask = __ballot(outpair);
-        if (start_mask != 0ull) status |= ST_HAD_OUTAGE;
+        status |= (start_mask != 0ull) ? ST_HAD_OUTAGE : 0;
         // is_sharp_turn_in_segment (ref :808-826): pair (i-1, i) exceeds the yaw-rate threshold (or has a bad quaternion)
         u64 f_mask = 0ull;
         if (pair_mask != 0ull) {
@@ -562,7 +553,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         }
         // recovery decision per recovering lane (ref :879-894)
         bool sharp = false;
-        if (recovers) {
+        if (rec_mask != 0ull && recovers) {                              // (wave-uniform test first: the usual chunk skips this with a scalar branch)
             const u64 sm = start_mask & bits(0, lane - 1);
             int64_t s_glob; bool seg;
             if (sm != 0ull) {
@@ -577,11 +568,10 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         }
         const u64 sharp_mask = __ballot(sharp);
         const u64 rts_mask = rec_mask & ~sharp_mask;                     // recoveries that run the RTS back-pass
-        if (sharp_mask != 0ull) status |= ST_SHARP_TURN;
-        if (rts_mask != 0ull) status |= ST_RTS_APPLIED;
+        status |= ((sharp_mask != 0ull) ? ST_SHARP_TURN : 0) | ((rts_mask != 0ull) ? ST_RTS_APPLIED : 0);
         // one-step blend weight on a sharp-turn recovery (ref :752-768, Q7): 1/eff if eff > 1, else a hard update
-        double wgt = 1.0;
-        if (sharp && cfg.sharp_turn_steps > 1) wgt = 1.0 / (double)cfg.sharp_turn_steps;
+        const double wgt_sharp = (cfg.sharp_turn_steps > 1) ? 1.0 / (double)cfg.sharp_turn_steps : 1.0;    // wave-uniform
+        const double wgt = sharp ? wgt_sharp : 1.0;
 
         // ---- orientation (ref :708-709) and predicted displacement (ref :707), telescoped form -- computed unconditionally, in the same
         // straight-line code as the variance scans below (independent work for the scheduler); a chunk that has to take the generic
@@ -608,6 +598,15 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
 
         if (telescope) cq_fresh = false;
         else {
+            // calculate_relative_pose, ref :77-92
+            if (!cq_fresh) { cq = quat_mul(Cq, c_r); cq_fresh = true; }  // the state quaternion the telescoped chunks did not carry
+            const Quat r1i = quat_conj(prev_lane(c_r, r));
+            Vec3 dpl = quat_rotate(r1i, Vec3{ p.x - p_pr.x, p.y - p_pr.y, p.z - p_pr.z });
+            Quat dq = quat_mul(r1i, r);
+            const bool move = stepping && both_ok;
+            dpl.x = move ? dpl.x : 0.0; dpl.y = move ? dpl.y : 0.0; dpl.z = move ? dpl.z : 0.0;
+            dq.x = move ? dq.x : 0.0; dq.y = move ? dq.y : 0.0; dq.z = move ? dq.z : 0.0; dq.w = move ? dq.w : 1.0;
+            if (__ballot(stepping && !both_ok) != 0ull) status |= ST_BAD_QUAT;
             // inclusive prefix product of the increments, q_i = normalize(q_carry * dq_first * ... * dq_i)
             Quat D = dq;
             const Quat QID{ 0.0, 0.0, 0.0, 1.0 };

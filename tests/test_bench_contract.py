@@ -45,7 +45,7 @@ def test_committed_traffic_profile_matches_the_kernel_sources():
     import bench
     doc = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
     assert doc["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/make_profiles.sh + tools/collect_profiles.py after changing a kernel"
-    got, src = bench.profiled_traffic("c2", "ekf_wave_kernel<true, true>", 64000)
+    got, src = bench.profiled_traffic("c2", "ekf_wave_kernel<true, true, 1>", 64000)
     assert src == "r02_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
 
 
