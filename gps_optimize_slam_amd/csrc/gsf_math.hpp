@@ -154,7 +154,7 @@ GSF_HD Quat quat_from_matrix(const double* M)
     else if (c == 1) { q[1] = 1.0 - tr + 2.0 * M[4]; q[2] = M[7] + M[5]; q[0] = M[1] + M[3]; q[3] = M[2] - M[6]; }
     else if (c == 2) { q[2] = 1.0 - tr + 2.0 * M[8]; q[0] = M[2] + M[6]; q[1] = M[5] + M[7]; q[3] = M[3] - M[1]; }
     else             { q[0] = M[7] - M[5]; q[1] = M[2] - M[6]; q[2] = M[3] - M[1]; q[3] = 1.0 + tr; }
-    double r = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double r = fast_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);   // >= 1 for a rotation matrix: never denormal
     return Quat{ q[0] * r, q[1] * r, q[2] * r, q[3] * r };
 }
 
@@ -396,11 +396,12 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
         }
         tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                               // (:444, Q12)
     }
-    double var_src = ssq / n;                                                  // (:443)
+    const double rcp_n = fast_rcp(n);                                          // n >= 3
+    double var_src = ssq * rcp_n;                                              // (:443)
     int32_t flags = SIM3_OK;
     if (var_src < 1e-12) { scale = 1.0; flags |= SIM3_FLAG_VAR0; }             // (:445-447)
     else {
-        scale = tr / (n * var_src);                                            // (:449)
+        scale = tr * fast_rcp(n * var_src);                                    // (:449)  n var_src >= 3e-12: normal range
         if (scale <= 1e-6) { scale = 1.0; flags |= SIM3_FLAG_SMALL_SCALE; }    // (:450)
     }
 #pragma unroll

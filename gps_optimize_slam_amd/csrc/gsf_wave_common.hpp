@@ -229,7 +229,7 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
     if (n >= 3.0) {                                                       // ref :430
         const Sums16 S = wave_sum16(sums[1], sums[2], sums[3], sums[4], sums[5], sums[6], sums[7], sums[8], sums[9], sums[10], sums[11],
                                     sums[12], sums[13], sums[14], sums[15], sums[16], lane);
-        const double rn = 1.0 / n;
+        const double rn = fast_rcp(n);                                    // n >= 3
         const double ma[3] = { S.v[0] * rn, S.v[1] * rn, S.v[2] * rn };
         const double mb[3] = { S.v[3] * rn, S.v[4] * rn, S.v[5] * rn };
         const double ssq = fmax(0.0, S.v[6] - n * (ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]));

@@ -51,6 +51,114 @@ __global__ void dpp_chain(double* out, long long* cyc, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
+// lane broadcast of a double through SGPRs (v_readlane x2, then used as a scalar operand) -- the carry pattern of the chunk loop
+__global__ void readlane_chain(double* out, long long* cyc, int iters)
+{
+    double x = threadIdx.x + 1.0, y = 0.5;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long b = __double_as_longlong(x);
+            const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+            const double s = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+            x = fma(y, s, x);                       // 3 instructions per step: readlane, readlane, fma with a scalar operand
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// compare -> lane mask in SGPRs -> select: the mask pattern of the outage logic
+__global__ void ballot_chain(double* out, long long* cyc, int iters)
+{
+    double x = threadIdx.x + 1.0;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(x > 3.0);
+            x = ((m >> (threadIdx.x & 63)) & 1ull) ? x * 0.999 : x + 1.0;      // v_cmp, s_lshr/s_and or v ops, v_cndmask ...
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// strided row loads like the chunk loop's (24-byte rows, one row per lane), dependent through the address
+__global__ void load_chain(const double* in, double* out, long long* cyc, int iters)
+{
+    const double* p = in + (size_t)blockIdx.x * 64 * 3 * 64;
+    double acc = 0;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        const double* q = p + (size_t)(i & 63) * 64 * 3 + threadIdx.x * 3;
+        acc += q[0] + q[1] + q[2];
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// the cross-row DPP controls of the scans: row_bcast:15 (0x142), row_bcast:31 (0x143), wave_shr:1 (0x138)
+template <int CTRL, int RM>
+__global__ void dppx_chain(double* out, long long* cyc, int iters)
+{
+    double x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = threadIdx.x + c;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long b = __double_as_longlong(x[c]);
+                const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, RM, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, RM, 0xf, false);
+                x[c] = fma(x[c], 0.5, __longlong_as_double(((long long)hi << 32) | (unsigned)lo));
+            }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// transcendental unit: v_rcp_f64 / v_rsq_f64 seeds, CH independent chains
+template <int CH>
+__global__ void trans_chain(double* out, long long* cyc, int iters)
+{
+    double x[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) x[c] = threadIdx.x + 1.5 + c;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) x[c] = __builtin_amdgcn_rcp(x[c]) + 1.25;     // v_rcp_f64 + v_add_f64
+    }
+    const long long t1 = clock64();
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) s += x[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// compare to a lane mask + select, independent of each other (4 per step)
+__global__ void cmp_sel(double* out, long long* cyc, int iters)
+{
+    double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x0 = (x0 > 3.0) ? x0 * 0.99 : x0 + 1.0; x1 = (x1 > 3.0) ? x1 * 0.99 : x1 + 1.0;
+            x2 = (x2 > 3.0) ? x2 * 0.99 : x2 + 1.0; x3 = (x3 > 3.0) ? x3 * 0.99 : x3 + 1.0;
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
 template <class K> void run(const char* name, K kern, int ch, int per_iter, int blocks, int threads)
 {
     double* d; long long* c; hipMalloc(&d, (size_t)blocks * threads * 8); hipMalloc(&c, 8);
@@ -64,7 +172,7 @@ template <class K> void run(const char* name, K kern, int ch, int per_iter, int 
 int main(int argc, char** argv)
 {
     const int wpb = argc > 1 ? atoi(argv[1]) : 1;
-    const int blocks = 1024 / wpb * 1, threads = 64 * wpb;        // ~one wave per SIMD chip-wide at wpb = 1 (blocks of one wave)
+    const int blocks = argc > 2 ? atoi(argv[2]) : 1024 / wpb, threads = 64 * wpb;   // default: ~one wave per SIMD chip-wide; 256 blocks of one wave: one wave per CU
     printf("blocks %d x %d threads\n", blocks, threads);
     run("v_fma_f64 dependent", fma_chain<1>, 1, 16, blocks, threads);
     run("v_fma_f64", fma_chain<2>, 2, 16, blocks, threads);
@@ -72,5 +180,21 @@ int main(int argc, char** argv)
     run("dpp mov x2 + fma (3 instr)", dpp_chain<1>, 1, 8 * 3, blocks, threads);
     run("dpp mov x2 + fma (3 instr)", dpp_chain<2>, 2, 8 * 3, blocks, threads);
     run("dpp mov x2 + fma (3 instr)", dpp_chain<4>, 4, 8 * 3, blocks, threads);
+    run("row_bcast:15 x2 + fma, 4 chains", dppx_chain<0x142, 0xa>, 4, 8 * 3, blocks, threads);
+    run("row_bcast:31 x2 + fma, 4 chains", dppx_chain<0x143, 0xc>, 4, 8 * 3, blocks, threads);
+    run("wave_shr:1 x2 + fma, 4 chains", dppx_chain<0x138, 0xf>, 4, 8 * 3, blocks, threads);
+    run("v_rcp_f64 + add (2 instr)", trans_chain<1>, 1, 8 * 2, blocks, threads);
+    run("v_rcp_f64 + add (2 instr)", trans_chain<4>, 4, 8 * 2, blocks, threads);
+    run("cmp + mul + add + 2 cndmask (x4)", cmp_sel, 1, 8 * 4, blocks, threads);
+    run("readlane x2 + fma (3 instr)", readlane_chain, 1, 8 * 3, blocks, threads);
+    run("ballot + select (per step)", ballot_chain, 1, 8, blocks, threads);
+    {
+        double* in; double* d; long long* c; hipMalloc(&in, (size_t)blocks * 64 * 3 * 64 * 8); hipMalloc(&d, (size_t)blocks * threads * 8); hipMalloc(&c, 8);
+        hipMemset(in, 0, (size_t)blocks * 64 * 3 * 64 * 8);
+        for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(load_chain, dim3(blocks), dim3(threads), 0, 0, in, d, c, 2000);
+        hipDeviceSynchronize();
+        long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+        printf("%-28s %.1f cycles per dependent row load (L2/L1 resident)\n", "24-byte row loads", (double)h / 2000.0);
+    }
     return 0;
 }
