@@ -122,6 +122,39 @@ __global__ void dppx_chain(double* out, long long* cyc, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
+// scalar ALU: dependent 64-bit mask arithmetic on a wave-uniform value (s_lshr_b64 / s_and_b64 / s_xor_b64 / s_add_u32 ...)
+__global__ void salu_chain(double* out, long long* cyc, int iters, unsigned long long seed)
+{
+    unsigned long long m = __builtin_amdgcn_readfirstlane((int)seed) | 0x123456789abcdefull;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            m = (m >> 1) ^ (m & 0x5555555555555555ull);
+            m = m + (unsigned long long)__builtin_popcountll(m);
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (double)m;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// wave-uniform branches: a chain of data-dependent (but uniform) conditional blocks
+__global__ void branch_chain(double* out, long long* cyc, int iters, unsigned long long seed)
+{
+    unsigned long long m = __builtin_amdgcn_readfirstlane((int)seed) | 0x9e3779b97f4a7c15ull;
+    double x = threadIdx.x;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if ((m >> u) & 1ull) x = fma(x, 1.0000001, 0.5); else x = fma(x, 0.9999999, 0.25);
+            m = m * 6364136223846793005ull + 1442695040888963407ull;
+        }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x + (double)m;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
 // transcendental unit: v_rcp_f64 / v_rsq_f64 seeds, CH independent chains
 template <int CH>
 __global__ void trans_chain(double* out, long long* cyc, int iters)
@@ -186,6 +219,15 @@ int main(int argc, char** argv)
     run("v_rcp_f64 + add (2 instr)", trans_chain<1>, 1, 8 * 2, blocks, threads);
     run("v_rcp_f64 + add (2 instr)", trans_chain<4>, 4, 8 * 2, blocks, threads);
     run("cmp + mul + add + 2 cndmask (x4)", cmp_sel, 1, 8 * 4, blocks, threads);
+    {
+        double* d; long long* c; hipMalloc(&d, (size_t)blocks * threads * 8); hipMalloc(&c, 8);
+        for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(salu_chain, dim3(blocks), dim3(threads), 0, 0, d, c, 2000, 12345ull);
+        hipDeviceSynchronize(); long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+        printf("%-28s %.2f cycles per step (shift, and, xor, popcount, add on 64-bit scalars)\n", "SALU dependent chain", (double)h / (2000.0 * 16));
+        for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(branch_chain, dim3(blocks), dim3(threads), 0, 0, d, c, 2000, 12345ull);
+        hipDeviceSynchronize(); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+        printf("%-28s %.2f cycles per uniform branch + fma + 64-bit scalar multiply-add\n", "uniform branches", (double)h / (2000.0 * 16));
+    }
     run("readlane x2 + fma (3 instr)", readlane_chain, 1, 8 * 3, blocks, threads);
     run("ballot + select (per step)", ballot_chain, 1, 8, blocks, threads);
     {
