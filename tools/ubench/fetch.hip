@@ -8,6 +8,10 @@ template <int UNROLL, bool BRANCHY>
 __global__ void big_loop(double* out, long long* cyc, int iters, int never)
 {
     double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    if (never <= -2) {                          // de-phase the waves: a block-dependent spin before the loop, so that the waves of a CU sit at different PCs
+        const int spin = (int)((blockIdx.x * 37u) % 61u) * 40;
+        for (int k = 0; k < spin; ++k) x3 = fma(x3, 1.0000001, 1e-9);
+    }
     const long long t0 = clock64();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -24,11 +28,11 @@ __global__ void big_loop(double* out, long long* cyc, int iters, int never)
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <class K> void run(const char* name, K kern, int instr_per_iter, int blocks)
+template <class K> void run(const char* name, K kern, int instr_per_iter, int blocks, int never = -1)
 {
     double* d; long long* c; hipMalloc(&d, (size_t)blocks * 64 * 8); hipMalloc(&c, 8);
     const int iters = 200;
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, d, c, iters, -1);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, d, c, iters, never);
     hipDeviceSynchronize();
     long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
     printf("  %-46s %.2f cycles per FMA\n", name, (double)h / ((double)iters * instr_per_iter));
@@ -41,5 +45,7 @@ int main(int argc, char** argv)
     run("64 FMAs per iteration (0.5 KB loop)", big_loop<16, false>, 64, blocks);
     run("2048 FMAs per iteration (16 KB loop)", big_loop<512, false>, 2048, blocks);
     run("2048 FMAs + a skipped block every 16 (branchy)", big_loop<512, true>, 2048, blocks);
+    run("16 KB loop, waves de-phased", big_loop<512, false>, 2048, blocks, -2);
+    run("branchy 16 KB loop, waves de-phased", big_loop<512, true>, 2048, blocks, -2);
     return 0;
 }
