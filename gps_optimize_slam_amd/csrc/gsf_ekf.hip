@@ -218,14 +218,14 @@ static int fuse_time_major_via_wave(gsf_ctx* ctx, bool pipeline, const double* t
     if (rc) return rc;
     double* wts = (double*)ctx->scratch; double* wpos = wts + P; double* wquat = wpos + 3 * P; double* wgps = wquat + 4 * P;
     double* wpo = wgps + 3 * P; double* wqo = wpo + 3 * P; uint8_t* wval = (uint8_t*)(wqo + 4 * P);
-    if ((rc = gsf_transpose_to_traj_major_dev(ctx, ts, wts, B, N, 1, 8))) return rc;
-    if ((rc = gsf_transpose_to_traj_major_dev(ctx, pos, wpos, B, N, 3, 8))) return rc;
-    if ((rc = gsf_transpose_to_traj_major_dev(ctx, quat, wquat, B, N, 4, 8))) return rc;
-    if ((rc = gsf_transpose_to_traj_major_dev(ctx, gps, wgps, B, N, 3, 8))) return rc;
-    if ((rc = gsf_transpose_to_traj_major_dev(ctx, valid, wval, B, N, 1, 1))) return rc;
+    // three launches: the five inputs in one transpose, the wave kernel, the two outputs in one transpose
+    const void* isrc[5] = { ts, pos, quat, gps, valid }; void* idst[5] = { wts, wpos, wquat, wgps, wval };
+    const int iC[5] = { 1, 3, 4, 3, 1 }, ib[5] = { 8, 8, 8, 8, 1 };
+    if ((rc = launch_transpose_set(ctx, false, 5, isrc, idst, iC, ib, B, N))) return rc;
     if ((rc = launch_ekf_wave(ctx, pipeline, wts, wpos, wquat, wgps, wval, init_pos, init_quat, cfg, B, N, R, t, s, wpo, wqo, status))) return rc;
-    if ((rc = gsf_transpose_to_time_major_dev(ctx, wpo, pos_out, B, N, 3, 8))) return rc;
-    return gsf_transpose_to_time_major_dev(ctx, wqo, quat_out, B, N, 4, 8);
+    const void* osrc[2] = { wpo, wqo }; void* odst[2] = { pos_out, quat_out };
+    const int oC[2] = { 3, 4 }, ob[2] = { 8, 8 };
+    return launch_transpose_set(ctx, true, 2, osrc, odst, oC, ob, B, N);
 }
 
 extern "C" int gsf_ekf_fuse_batch_dev(gsf_ctx* ctx, int32_t layout, const double* ts, const double* pos, const double* quat,

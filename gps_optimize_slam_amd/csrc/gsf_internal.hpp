@@ -95,4 +95,5 @@ private:
     int rc_ = GSF_OK; Out outs_[MAX_OUT]; int n_out_ = 0;
 };
 
+int launch_transpose_set(gsf_ctx* ctx, bool to_time, int n, const void* const* src, void* const* dst, const int* C, const int* elem_bytes, int64_t B, int64_t N);
 }  // namespace gsf

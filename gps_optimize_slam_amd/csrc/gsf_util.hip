@@ -38,6 +38,40 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
     }
 }
 
+// Several arrays of one batch in ONE launch (the time-major route through the wave kernel transposes five inputs and two outputs; at
+// small batches each extra launch costs more than the copy itself).  blockIdx.z walks the components of all arrays: segment k holds
+// comp[k] .. comp[k+1]-1.  8-byte elements, except a segment flagged as bytes.
+struct TransposeSet { const void* src[5]; void* dst[5]; int C[5]; int comp0[6]; int bytes[5]; int n; };
+template <bool TO_TIME>
+__global__ __launch_bounds__(256) void transpose_set_kernel(TransposeSet ts, int64_t B, int64_t N)
+{
+    __shared__ double tile[64][65];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (j < ts.n && (int)blockIdx.z >= ts.comp0[j]) k = j;
+    const int c = (int)blockIdx.z - ts.comp0[k], C = ts.C[k];
+    const int64_t b0 = (int64_t)blockIdx.x * 64, i0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bool by = ts.bytes[k] != 0;
+    const double* sd = (const double*)ts.src[k]; double* dd = (double*)ts.dst[k];
+    const uint8_t* sb = (const uint8_t*)ts.src[k]; uint8_t* db = (uint8_t*)ts.dst[k];
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t b = TO_TIME ? b0 + r : b0 + tx, i = TO_TIME ? i0 + tx : i0 + r;
+        if (b < B && i < N) {
+            const int64_t at = TO_TIME ? (b * N + i) * C + c : (i * C + c) * B + b;
+            tile[r][tx] = by ? (double)sb[at] : sd[at];
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t i = TO_TIME ? i0 + r : i0 + tx, b = TO_TIME ? b0 + tx : b0 + r;
+        if (b < B && i < N) {
+            const int64_t at = TO_TIME ? (i * C + c) * B + b : (b * N + i) * C + c;
+            if (by) db[at] = (uint8_t)tile[tx][r]; else dd[at] = tile[tx][r];
+        }
+    }
+}
+
 template <bool TO_TIME>
 int launch_transpose(gsf_ctx* ctx, const void* src, void* dst, int64_t B, int64_t N, int32_t C, int32_t elem_bytes)
 {
@@ -55,6 +89,25 @@ int launch_transpose(gsf_ctx* ctx, const void* src, void* dst, int64_t B, int64_
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
+
+}  // namespace
+namespace gsf {
+// n arrays ([B][N][C_k] <-> [N][C_k][B]) in one launch; elem_bytes[k] is 8 or 1
+int launch_transpose_set(gsf_ctx* ctx, bool to_time, int n, const void* const* src, void* const* dst, const int* C, const int* elem_bytes, int64_t B, int64_t N)
+{
+    if (B == 0 || N == 0 || n == 0) return GSF_OK;
+    GSF_REQUIRE(n >= 1 && n <= 5 && (N + 63) / 64 <= 65535, "bad transpose set");
+    TransposeSet ts{};
+    ts.n = n; ts.comp0[0] = 0;
+    for (int k = 0; k < n; ++k) { ts.src[k] = src[k]; ts.dst[k] = dst[k]; ts.C[k] = C[k]; ts.bytes[k] = elem_bytes[k] == 1; ts.comp0[k + 1] = ts.comp0[k] + C[k]; }
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)ts.comp0[n]), block(256);
+    if (to_time) hipLaunchKernelGGL(transpose_set_kernel<true>, grid, block, 0, ctx->stream, ts, B, N);
+    else hipLaunchKernelGGL(transpose_set_kernel<false>, grid, block, 0, ctx->stream, ts, B, N);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+}  // namespace gsf
+namespace {
 
 // ---- counter-based RNG: integer hash -> uniform double; no libm, so values do not depend on a math library
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
