@@ -88,8 +88,13 @@ __global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double*
     // ---- segments (:348-352), processed one after the other (usually 1-3 per track)
     int seg_s = 0;
     while (seg_s < nu) {
-        int seg_e = seg_s;                                               // wave-uniform scan for the end of the segment
-        while (seg_e + 1 < nu && !(T[seg_e + 1] - T[seg_e] > max_gap)) ++seg_e;
+        // end of the segment = first k >= seg_s with T[k+1] - T[k] > max_gap (or the last fix): 64 gaps per step, first set bit of the ballot
+        int seg_e = nu - 1;
+        for (int k0 = seg_s; k0 + 1 < nu; k0 += ALIGN_THREADS) {
+            const int k = k0 + lane;
+            const unsigned long long gaps = __ballot(k + 1 < nu && (T[k + 1] - T[k] > max_gap));
+            if (gaps != 0ull) { seg_e = k0 + __ffsll((long long)gaps) - 1; break; }
+        }
         const int m = seg_e - seg_s + 1;
         if (m >= 2) {                                                    // :360
             bool inc = true;
@@ -103,26 +108,60 @@ __global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double*
                 if (cubic) {
                     // knot second derivatives M_0..M_{m-1}:  h[i-1] M[i-1] + 2(h[i-1]+h[i]) M[i] + h[i] M[i+1] = 6 (d[i]-d[i-1]),
                     // not-a-knot ends folded into the first / last interior row.  Lanes 0..2 = components; c' is shared.
+                    // right-hand sides 6 (d[i+1] - d[i]), d = divided differences: independent per row, all lanes (their divisions were
+                    // most of the serial sweep's time); parked where the sweep leaves d'_i
+                    const int kk = m - 2;
+                    for (int i = lane; i < kk; i += ALIGN_THREADS) {
+                        const double hl = x[i + 1] - x[i], hr = x[i + 2] - x[i + 1];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            Ms[(i + 1) * 3 + c] = 6.0 * ((y[(i + 2) * 3 + c] - y[(i + 1) * 3 + c]) / hr - (y[(i + 1) * 3 + c] - y[i * 3 + c]) / hl);
+                    }
+                    __syncthreads();
                     if (lane < 3) {
-                        const int c = lane, kk = m - 2;
+                        const int c = lane;
                         double* cp = W + seg_s;                          // c'_i of the forward sweep
                         const double r0 = (x[1] - x[0]) / (x[2] - x[1]);
                         const double r1 = (x[m - 1] - x[m - 2]) / (x[m - 2] - x[m - 3]);
                         double cprev = 0.0, dprev = 0.0;
-                        for (int i = 0; i < kk; ++i) {                   // interior unknown i+1
-                            const double hl = x[i + 1] - x[i], hr = x[i + 2] - x[i + 1];
-                            double aa = hl, bb = 2.0 * (hl + hr), cc = hr;
-                            const double rhs = 6.0 * ((y[(i + 2) * 3 + c] - y[(i + 1) * 3 + c]) / hr - (y[(i + 1) * 3 + c] - y[i * 3 + c]) / hl);
-                            if (i == 0) { bb += aa * (1.0 + r0); cc -= aa * r0; aa = 0.0; }
-                            if (i == kk - 1) { bb += cc * (1.0 + r1); aa -= cc * r1; cc = 0.0; }
-                            const double den = bb - aa * cprev;
-                            const double cn = cc / den, dn = (rhs - aa * dprev) / den;
-                            cp[i] = cn;                                  // the three lanes store the same value
-                            Ms[(i + 1) * 3 + c] = dn;                    // d'_i for now
-                            cprev = cn; dprev = dn;
+                        double xa = x[0], xb = x[1];
+                        // rows in blocks of eight: their knots and right-hand sides are read from LDS before the dependent chain
+                        // (c', d' recurrences: one fma, one reciprocal, two multiplies per row) starts on them
+                        for (int i0 = 0; i0 < kk; i0 += 8) {
+                            double xs[8], rh[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int i = (i0 + u < kk) ? i0 + u : kk - 1;
+                                xs[u] = x[i + 2]; rh[u] = Ms[(i + 1) * 3 + c];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int i = i0 + u;
+                                if (i < kk) {                             // uniform over the three lanes
+                                    const double xc = xs[u];
+                                    const double hl = xb - xa, hr = xc - xb;
+                                    xa = xb; xb = xc;
+                                    double aa = hl, bb = 2.0 * (hl + hr), cc = hr;
+                                    if (i == 0) { bb += aa * (1.0 + r0); cc -= aa * r0; aa = 0.0; }
+                                    if (i == kk - 1) { bb += cc * (1.0 + r1); aa -= cc * r1; cc = 0.0; }
+                                    const double rden = fast_rcp(bb - aa * cprev);   // diagonally dominant rows: den ~ 2 (hl + hr), far from denormal
+                                    const double cn = cc * rden, dn = (rh[u] - aa * dprev) * rden;
+                                    cp[i] = cn;                          // the three lanes store the same value
+                                    Ms[(i + 1) * 3 + c] = dn;            // d'_i for now
+                                    cprev = cn; dprev = dn;
+                                }
+                            }
                         }
                         double xn = 0.0;
-                        for (int i = kk - 1; i >= 0; --i) {              // back substitution
+                        int i = kk - 1;
+                        for (; i >= 7; i -= 8) {                         // back substitution, eight rows' d' and c' read ahead of the dependent chain
+                            double dd[8], cq[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { dd[u] = Ms[(i - u + 1) * 3 + c]; cq[u] = cp[i - u]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { xn = dd[u] - cq[u] * xn; Ms[(i - u + 1) * 3 + c] = xn; }
+                        }
+                        for (; i >= 0; --i) {
                             const double xi = Ms[(i + 1) * 3 + c] - cp[i] * xn;
                             Ms[(i + 1) * 3 + c] = xi; xn = xi;
                         }
