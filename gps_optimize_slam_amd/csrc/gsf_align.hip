@@ -11,6 +11,8 @@
 //      stamps outside [t0, t1] get NaN like interp1d(bounds_error=False, fill_value=nan); valid = all three finite (:377-379).
 // The clock-offset estimate of :336 is identically 0 and is not computed.
 #include "gsf_internal.hpp"
+#include "gsf_ekf_core.hpp"
+#include "gsf_wave_common.hpp"   // DPP scan stages, lane broadcasts
 
 using namespace gsf;
 
@@ -136,53 +138,64 @@ __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __re
                             Ms[(i + 1) * 3 + c] = 6.0 * ((y[(i + 2) * 3 + c] - y[(i + 1) * 3 + c]) / hr - (y[(i + 1) * 3 + c] - y[i * 3 + c]) / hl);
                     }
                     __syncthreads();
+                    // The tridiagonal solve as three prefix scans over the rows (64 per step, all lanes), instead of two serial sweeps on
+                    // three lanes: with rows scaled by 1/b_i, the forward elimination's c'_i = c_i / (1 - a_i c'_{i-1}) is a Moebius
+                    // recurrence (2x2 matrix prefix products), d'_i = (r_i - a_i d'_{i-1}) / (b_i - a_i c'_{i-1}) is affine in d'_{i-1}
+                    // once the c' are known (one multiplier for the three components), and the back substitution
+                    // M_i = d'_i - c'_i M_{i+1} is affine in reverse order.  Rows are diagonally dominant (|a| + |c| <= b / 2 inside, the
+                    // not-a-knot ends included for increasing stamps), so the products stay O(1).
+                    const double r0 = (x[1] - x[0]) / (x[2] - x[1]);
+                    const double r1 = (x[m - 1] - x[m - 2]) / (x[m - 2] - x[m - 3]);
+                    StagePtr cp = W + seg_s;                             // c'_i
+                    double c_in = 0.0, d_in0 = 0.0, d_in1 = 0.0, d_in2 = 0.0;
+                    for (int c0 = 0; c0 < kk; c0 += ALIGN_THREADS) {
+                        const int i = c0 + lane;
+                        const bool act = i < kk;
+                        const int ic = act ? i : kk - 1;
+                        const double hl = x[ic + 1] - x[ic], hr = x[ic + 2] - x[ic + 1];
+                        double aa = hl, bb = 2.0 * (hl + hr), cc = hr;
+                        if (ic == 0) { bb += aa * (1.0 + r0); cc -= aa * r0; aa = 0.0; }
+                        if (ic == kk - 1) { bb += cc * (1.0 + r1); aa -= cc * r1; cc = 0.0; }
+                        const double rb = fast_rcp(bb);
+                        // f_i(c) = (0 c + cc/bb) / (-(aa/bb) c + 1); idle lanes carry the identity map
+                        double A = act ? 0.0 : 1.0, Bm = act ? cc * rb : 0.0, Cm = act ? -(aa * rb) : 0.0, Dm = 1.0;
+#define GSF_AL_MSTAGE(CTRL, RM) {                                                                                              \
+                        const double oA = dpp<CTRL, RM>(1.0, A), oB = dpp0<CTRL, RM>(Bm), oC = dpp0<CTRL, RM>(Cm), oD = dpp<CTRL, RM>(1.0, Dm); \
+                        const double nA = A * oA + Bm * oC, nB = A * oB + Bm * oD, nC = Cm * oA + Dm * oC, nD = Cm * oB + Dm * oD;                  \
+                        A = nA; Bm = nB; Cm = nC; Dm = nD; }
+                        GSF_SCAN_STAGES(GSF_AL_MSTAGE)
+#undef GSF_AL_MSTAGE
+                        const double cpi = (A * c_in + Bm) * fast_rcp(Cm * c_in + Dm);
+                        const double cprev = prev_lane(c_in, cpi);
+                        const double rden = fast_rcp(bb - aa * cprev);
+                        double al = act ? -(aa * rden) : 1.0;
+                        double be0 = act ? Ms[(ic + 1) * 3] * rden : 0.0, be1 = act ? Ms[(ic + 1) * 3 + 1] * rden : 0.0, be2 = act ? Ms[(ic + 1) * 3 + 2] * rden : 0.0;
+#define GSF_AL_ASTAGE(CTRL, RM) { const double oa = dpp<CTRL, RM>(1.0, al), o0 = dpp0<CTRL, RM>(be0), o1 = dpp0<CTRL, RM>(be1), o2 = dpp0<CTRL, RM>(be2); \
+                                  be0 = al * o0 + be0; be1 = al * o1 + be1; be2 = al * o2 + be2; al = al * oa; }
+                        GSF_SCAN_STAGES(GSF_AL_ASTAGE)
+                        const double dp0 = al * d_in0 + be0, dp1 = al * d_in1 + be1, dp2 = al * d_in2 + be2;
+                        if (act) { cp[i] = cpi; Ms[(i + 1) * 3] = dp0; Ms[(i + 1) * 3 + 1] = dp1; Ms[(i + 1) * 3 + 2] = dp2; }
+                        const int L = (kk - c0 < ALIGN_THREADS) ? (kk - c0 - 1) : ALIGN_THREADS - 1;
+                        c_in = lane_bcast(cpi, L); d_in0 = lane_bcast(dp0, L); d_in1 = lane_bcast(dp1, L); d_in2 = lane_bcast(dp2, L);
+                    }
+                    __syncthreads();
+                    double x_in0 = 0.0, x_in1 = 0.0, x_in2 = 0.0;
+                    for (int c0 = 0; c0 < kk; c0 += ALIGN_THREADS) {         // back substitution, rows in reverse: j = kk-1-i
+                        const int j = c0 + lane;
+                        const bool act = j < kk;
+                        const int i = act ? kk - 1 - j : 0;
+                        double al = act ? -cp[i] : 1.0;
+                        double be0 = act ? Ms[(i + 1) * 3] : 0.0, be1 = act ? Ms[(i + 1) * 3 + 1] : 0.0, be2 = act ? Ms[(i + 1) * 3 + 2] : 0.0;
+                        GSF_SCAN_STAGES(GSF_AL_ASTAGE)
+#undef GSF_AL_ASTAGE
+                        const double m0 = al * x_in0 + be0, m1 = al * x_in1 + be1, m2 = al * x_in2 + be2;
+                        if (act) { Ms[(i + 1) * 3] = m0; Ms[(i + 1) * 3 + 1] = m1; Ms[(i + 1) * 3 + 2] = m2; }
+                        const int L = (kk - c0 < ALIGN_THREADS) ? (kk - c0 - 1) : ALIGN_THREADS - 1;
+                        x_in0 = lane_bcast(m0, L); x_in1 = lane_bcast(m1, L); x_in2 = lane_bcast(m2, L);
+                    }
+                    __syncthreads();
                     if (lane < 3) {
                         const int c = lane;
-                        StagePtr cp = W + seg_s;                         // c'_i of the forward sweep
-                        const double r0 = (x[1] - x[0]) / (x[2] - x[1]);
-                        const double r1 = (x[m - 1] - x[m - 2]) / (x[m - 2] - x[m - 3]);
-                        double cprev = 0.0, dprev = 0.0;
-                        double xa = x[0], xb = x[1];
-                        // rows in blocks of eight: their knots and right-hand sides are read from LDS before the dependent chain
-                        // (c', d' recurrences: one fma, one reciprocal, two multiplies per row) starts on them
-                        for (int i0 = 0; i0 < kk; i0 += 8) {
-                            double xs[8], rh[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const int i = (i0 + u < kk) ? i0 + u : kk - 1;
-                                xs[u] = x[i + 2]; rh[u] = Ms[(i + 1) * 3 + c];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const int i = i0 + u;
-                                if (i < kk) {                             // uniform over the three lanes
-                                    const double xc = xs[u];
-                                    const double hl = xb - xa, hr = xc - xb;
-                                    xa = xb; xb = xc;
-                                    double aa = hl, bb = 2.0 * (hl + hr), cc = hr;
-                                    if (i == 0) { bb += aa * (1.0 + r0); cc -= aa * r0; aa = 0.0; }
-                                    if (i == kk - 1) { bb += cc * (1.0 + r1); aa -= cc * r1; cc = 0.0; }
-                                    const double rden = fast_rcp(bb - aa * cprev);   // diagonally dominant rows: den ~ 2 (hl + hr), far from denormal
-                                    const double cn = cc * rden, dn = (rh[u] - aa * dprev) * rden;
-                                    cp[i] = cn;                          // the three lanes store the same value
-                                    Ms[(i + 1) * 3 + c] = dn;            // d'_i for now
-                                    cprev = cn; dprev = dn;
-                                }
-                            }
-                        }
-                        double xn = 0.0;
-                        int i = kk - 1;
-                        for (; i >= 7; i -= 8) {                         // back substitution, eight rows' d' and c' read ahead of the dependent chain
-                            double dd[8], cq[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) { dd[u] = Ms[(i - u + 1) * 3 + c]; cq[u] = cp[i - u]; }
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) { xn = dd[u] - cq[u] * xn; Ms[(i - u + 1) * 3 + c] = xn; }
-                        }
-                        for (; i >= 0; --i) {
-                            const double xi = Ms[(i + 1) * 3 + c] - cp[i] * xn;
-                            Ms[(i + 1) * 3 + c] = xi; xn = xi;
-                        }
                         Ms[c] = Ms[3 + c] * (1.0 + r0) - Ms[6 + c] * r0;
                         Ms[(m - 1) * 3 + c] = Ms[(m - 2) * 3 + c] * (1.0 + r1) - Ms[(m - 3) * 3 + c] * r1;
                     }
