@@ -78,6 +78,10 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     const int64_t* offsets)
 {
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
+    // tracks of 65..1024 poses: one workgroup per trajectory, one wave per chunk (gsf_ekf_block.hip).  The choice depends on N and the
+    // layout only, never on B, so a shard of a batch produces the same bits as the whole batch.
+    if (ctx->block_kernel == 1 && ekf_block_applies(N, offsets))
+        return launch_ekf_block(ctx, pipeline, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status);
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
     const EkfConfig k = to_core(cfg);
     // x and y share their (P0, Q, R) and z does not (the default CONFIG): the build with that choice of scans compiled in

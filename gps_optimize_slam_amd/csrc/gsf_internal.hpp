@@ -21,6 +21,7 @@ struct gsf_ctx {
     void* pinned;
     size_t pinned_bytes;
     int ekf_variant;       // reserved tuning knob (gsf_set_option "ekf_variant"); 0 = default
+    int block_kernel;      // workgroup-per-trajectory kernel for 64 < N <= 1024 (gsf_set_option "block_kernel"): -1 automatic, 0 never, 1 always
     int duo_kernel;        // two-wave pipeline kernel for small batches (gsf_set_option "duo_kernel"): -1 automatic, 0 never, 1 always
     int64_t lane_min_traj; // time-major batches with fewer trajectories are transposed and run by the wave kernel (gsf_set_option "lane_min_traj")
 };
@@ -59,6 +60,12 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
                     const int64_t* offsets = nullptr);
+
+// workgroup-per-trajectory K4 / fused pipeline (gsf_ekf_block.hip): one wave per 64-pose chunk, every input byte read once
+bool ekf_block_applies(int64_t N, const int64_t* offsets);
+int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
+                     const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
+                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
 
 // K2b launch with optional per-set row counts (sets in fixed-stride slots: rows offsets[b] .. offsets[b] + counts[b])
 int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,

@@ -269,6 +269,8 @@ GSF_HD double sumsq9(const double* M)
 {
     return M[0] * M[0] + M[1] * M[1] + M[2] * M[2] + M[3] * M[3] + M[4] * M[4] + M[5] * M[5] + M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
 }
+// LOWREG: cof(X0) is not kept across the Newton steps but formed again (same operations, same bits) by the rare branch that needs it
+template <bool LOWREG = false>
 GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma)
 {
     const double nh2 = sumsq9(H);
@@ -334,6 +336,12 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
         if (!(e0 < 3e-3 * nc20)) {
             // weakly separated (e up to 0.33): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
             // that v3 v3^T dominates by e^64; v3 is its largest column
+            if (LOWREG) {
+                double X0[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) X0[i] = H[i] * rn;
+                cof3(X0, C0);
+            }
             double b00 = C0[0] * C0[0] + C0[3] * C0[3] + C0[6] * C0[6], b01 = C0[0] * C0[1] + C0[3] * C0[4] + C0[6] * C0[7],
                    b02 = C0[0] * C0[2] + C0[3] * C0[5] + C0[6] * C0[8], b11 = C0[1] * C0[1] + C0[4] * C0[4] + C0[7] * C0[7],
                    b12 = C0[1] * C0[2] + C0[4] * C0[5] + C0[7] * C0[8], b22 = C0[2] * C0[2] + C0[5] * C0[5] + C0[8] * C0[8];
@@ -367,10 +375,41 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
 // status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
 enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8 };
 
+// the SVD route of the closed form's rotation, ref :439-444: R = Vt.T @ U.T with the reflection fix, tr = S0 + S1 + S2 det(R)
+GSF_HD void umeyama_rotation_svd(const double* H, double* R, double& tr)
+{
+    Svd3 s; svd3(H, s);
+    // R = Vt.T @ U.T = V U^T                                               (:440)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] + s.V[r * 3 + 2] * s.U[c * 3 + 2];
+    if (det3(R) < 0.0) {                                                   // (:441-442) flip last row of Vt
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] - s.V[r * 3 + 2] * s.U[c * 3 + 2];
+    }
+    tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                               // (:444, Q12)
+}
+// the same as a real CALL (arguments through memory): for kernels whose register budget must not pay for the rare fallback
+struct SvdRot { double R[9], tr; };
+GSF_HD_COLD void umeyama_rotation_svd_cold(const double* H, SvdRot* out)
+{
+    double Hc[9], R[9], tr;
+    for (int i = 0; i < 9; ++i) Hc[i] = H[i];
+    umeyama_rotation_svd(Hc, R, tr);
+    for (int i = 0; i < 9; ++i) out->R[i] = R[i];
+    out->tr = tr;
+}
+
 // Umeyama closed form from the reduced moments, ref :439-451.
 //   H = sum src_c dst_c^T (row-major), ssq = sum |src_c|^2, sc/dc centroids, n points.
 // POLAR: take the rotation from umeyama_rotation_polar when it applies (the fused pipeline; identical to the SVD route to ~1e-14).
-template <bool POLAR = false>
+// COLD_SVD: the SVD fallback of the POLAR route is a call instead of inline code (same arithmetic).
+template <bool POLAR = false, bool COLD_SVD = false>
 GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, const double* dc, double n,
                                 double* R, double* t, double& scale)
 {
@@ -379,22 +418,18 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
     for (int i = 0; i < 9; ++i) finite = finite && (fabs(H[i]) < INFINITY);   // NaN/inf -> LinAlgError -> None (:452)
     if (!finite) return SIM3_NONE;
     double tr = 0.0;
-    if (!(POLAR && umeyama_rotation_polar(H, R, tr))) {                        // tr: S0+S1+S2 (det(R) = 1 to rounding, Q12)
-        Svd3 s; svd3(H, s);
-        // R = Vt.T @ U.T = V U^T                                               (:440)
+    if (!(POLAR && umeyama_rotation_polar<COLD_SVD>(H, R, tr))) {                        // tr: S0+S1+S2 (det(R) = 1 to rounding, Q12)
+        if (COLD_SVD) {
+            double Hm[9]; SvdRot o;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+            umeyama_rotation_svd_cold(Hm, &o);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] + s.V[r * 3 + 2] * s.U[c * 3 + 2];
-        if (det3(R) < 0.0) {                                                   // (:441-442) flip last row of Vt
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    R[r * 3 + c] = s.V[r * 3 + 0] * s.U[c * 3 + 0] + s.V[r * 3 + 1] * s.U[c * 3 + 1] - s.V[r * 3 + 2] * s.U[c * 3 + 2];
+            for (int i = 0; i < 9; ++i) R[i] = o.R[i];
+            tr = o.tr;
+        } else {
+            umeyama_rotation_svd(H, R, tr);
         }
-        tr = s.S[0] + s.S[1] + s.S[2] * det3(R);                               // (:444, Q12)
     }
     const double rcp_n = fast_rcp(n);                                          // n >= 3
     double var_src = ssq * rcp_n;                                              // (:443)

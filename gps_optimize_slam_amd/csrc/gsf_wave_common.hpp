@@ -93,8 +93,10 @@ template <int D> __device__ __forceinline__ double dpp_row_xor(double v)
     hi = __builtin_amdgcn_update_dpp(hi, (int)(x >> 32), SHR, 0xf, HIGH_BANKS, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ Sums16 wave_sum16(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7,
-                                            double a8, double a9, double a10, double a11, double a12, double a13, double a14, double a15, int lane)
+// first half: the exchanges inside a 16-lane row.  Afterwards lane l holds the sum over ITS ROW of the value whose index is the bit
+// reversal of l & 15 (the block-per-trajectory kernel adds these per-row values of all its waves through LDS before the second half)
+__device__ __forceinline__ double row_sums16_transposed(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7,
+                                                        double a8, double a9, double a10, double a11, double a12, double a13, double a14, double a15, int lane)
 {
     const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
     // keep the half selected by my bit, hand the other half to the partner, add what the partner hands over
@@ -108,9 +110,14 @@ __device__ __forceinline__ Sums16 wave_sum16(double a0, double a1, double a2, do
                  x3 = GSF_BFLY(b1, w3, w7, dpp_quad<0x4E>);
     // stage 3 (lane ^ 4): 4 -> 2;  stage 4 (lane ^ 8): 2 -> 1
     const double y0 = GSF_BFLY(b2, x0, x2, dpp_row_xor<4>), y1 = GSF_BFLY(b2, x1, x3, dpp_row_xor<4>);
-    double z = GSF_BFLY(b3, y0, y1, dpp_row_xor<8>);
+    const double z = GSF_BFLY(b3, y0, y1, dpp_row_xor<8>);
 #undef GSF_BFLY
-    // lane l now holds the sum over its 16-lane row of value index 8 b0 + 4 b1 + 2 b2 + b3; add the four rows
+    return z;
+}
+// second half: add the four rows, broadcast the sixteen totals
+__device__ __forceinline__ Sums16 sums16_finish(double z)
+{
+    // lane l holds the sum over its 16-lane row of value index 8 b0 + 4 b1 + 2 b2 + b3; add the four rows
     z += __shfl_xor(z, 16, 64);
     z += __shfl_xor(z, 32, 64);
     Sums16 r;
@@ -120,6 +127,11 @@ __device__ __forceinline__ Sums16 wave_sum16(double a0, double a1, double a2, do
     GSF_OUT(8) GSF_OUT(9) GSF_OUT(10) GSF_OUT(11) GSF_OUT(12) GSF_OUT(13) GSF_OUT(14) GSF_OUT(15)
 #undef GSF_OUT
     return r;
+}
+__device__ __forceinline__ Sums16 wave_sum16(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7,
+                                            double a8, double a9, double a10, double a11, double a12, double a13, double a14, double a15, int lane)
+{
+    return sums16_finish(row_sums16_transposed(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, lane));
 }
 
 // bits lo..hi (inclusive) of a 64-bit mask; empty if lo > hi
@@ -363,7 +375,10 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
 // axis, carry-in cP.  Axes with identical (P0, Q, R) have identical recursions and reuse the scan (default CONFIG: x == y).
 // One function for the chunked body AND the helper wave of the two-wave kernel, so that both produce the same bits.
 struct AxisVar { double Pf, Pm, kg; };
-__device__ __forceinline__ AxisVar variance_axis(const double q, const double rr, const double dt, const bool stepping, const bool avail, const double cPc)
+// the scan on its own (identity carry): lane i holds the composition of the maps of poses first..i of the chunk; lanes that do not
+// step hold the identity, so lane 63 always holds the chunk's total
+struct Moebius { double A, B, C, D; };
+__device__ __forceinline__ Moebius variance_scan(const double q, const double rr, const double dt, const bool stepping, const bool avail)
 {
     const double b0 = q * dt;
     double A = 1.0, Bm = stepping ? b0 : 0.0, Cm = 0.0, Dm = 1.0;
@@ -375,11 +390,21 @@ __device__ __forceinline__ AxisVar variance_axis(const double q, const double rr
         A = nA; Bm = nB; Cm = nC; Dm = nD; }
     GSF_SCAN_STAGES(GSF_MSTAGE)
 #undef GSF_MSTAGE
+    return Moebius{ A, Bm, Cm, Dm };
+}
+__device__ __forceinline__ double moebius_apply(const Moebius& m, const double P) { return (m.A * P + m.B) * fast_rcp(m.C * P + m.D); }
+// carry-in cPc applied: filtered / predicted variance and the Kalman gain of every pose of the chunk
+__device__ __forceinline__ AxisVar variance_finish(const Moebius& m, const double q, const double rr, const double dt, const double cPc)
+{
     AxisVar v;
-    v.Pf = (A * cPc + Bm) * fast_rcp(Cm * cPc + Dm);                     // P_f[i]
-    v.Pm = prev_lane(cPc, v.Pf) + b0;                                    // P_p[i]
+    v.Pf = moebius_apply(m, cPc);                                        // P_f[i]
+    v.Pm = prev_lane(cPc, v.Pf) + q * dt;                                // P_p[i]
     v.kg = v.Pm * fast_rcp(v.Pm + rr);                                   // Kalman gain if the fix is used
     return v;
+}
+__device__ __forceinline__ AxisVar variance_axis(const double q, const double rr, const double dt, const bool stepping, const bool avail, const double cPc)
+{
+    return variance_finish(variance_scan(q, rr, dt, stepping, avail), q, rr, dt, cPc);
 }
 // (scalar arguments and constant indices only: a helper that indexes its caller's arrays dynamically puts them into scratch)
 __device__ __forceinline__ void variance_chunk(const EkfConfig& cfg, const int same1, const int same2, const double dt, const bool stepping,
