@@ -56,15 +56,24 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
+    # rank 0 prints the line; every rank gets a deadline (a stalled communicator must not hang the parent: the ranks' own watchdog
+    # fires first and exits non-zero, this is the backstop)
+    limit = float(os.environ.get("GSF_BENCH_RANK_TIMEOUT_S", "900"))
+    try:
+        out0, _ = procs[0].communicate(timeout=limit)
+        rc = procs[0].returncode
+    except subprocess.TimeoutExpired:
+        procs[0].kill()
+        out0, _ = procs[0].communicate()
+        rc = 124
     deadline = time.time() + 120
     for p in procs[1:]:
         try:
             p.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
             p.kill()
-        rc = rc or p.returncode
+            p.wait()
+        rc = rc or p.returncode or (124 if p.returncode is None else 0)
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     return rc
@@ -201,7 +210,11 @@ def profiled_traffic(workload, kernel, grid_threads):
 # ----------------------------------------------------------------------------------------------------------------------
 # C5-shaped leg: fuse a big per-GPU shard chunk by chunk, all-gather every chunk's poses while the next chunk is fused
 # ----------------------------------------------------------------------------------------------------------------------
-def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N, passes=1, stall_cb=None, stall_seconds=240.0):
+STALL_EXIT_CODE = 3                # a rank whose collect leg stalled has printed what it had and leaves with this code
+
+
+def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N, passes=1, stall_cb=None, stall_seconds=240.0,
+           leg_budget_s=150.0, inject_stall_s=0.0):
     import ctypes as C
     import threading
 
@@ -281,65 +294,91 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
     legs = [("torch_all_gather", None)]
     if not rehearsal:
         legs += [("gsf_ncclAllGather", 0), ("gsf_direct_sendrecv", 1)]
-    collector, watchdog = None, None
+    collector = None
     info["collect"] = {}
-    for name, mode in legs:
-        if mode is not None and collector is None:
-            # The library's own communicator has never met a second GPU before an 8-GPU node runs this (one GPU per build box).  A
-            # watchdog guards the legs that use it: if set-up or an exchange stalls, every rank reports what it has (rank 0 prints
-            # the JSON line through stall_cb) and leaves -- the torch.distributed leg above is already in `info`.
-            def on_stall():
-                info["own_communicator_error"] = f"watchdog: the library's RCCL communicator did not finish within {stall_seconds:.0f} s"
-                if stall_cb is not None:
-                    stall_cb(info)
-                os._exit(0)
-            watchdog = threading.Timer(stall_seconds, on_stall)
-            watchdog.daemon = True
-            watchdog.start()
-            try:
+    info["backend"] = torch.distributed.get_backend()
+    # a-priori budget: a leg moves recv_per_rank bytes into every GPU; at a pessimistic 30 GB/s per xGMI link (a fifth of the 153 GB/s
+    # link rate) that is the time below.  Passes are cut so that one leg stays inside leg_budget_s; legs that would start after the
+    # budget of all three is spent are skipped and say so.
+    est_pass_s = recv_per_rank / (max(1, world - 1) * 30e9) + 2.0 * info["compute_only"]["ms"] * 1e-3
+    passes = max(1, min(passes, int(leg_budget_s / max(est_pass_s, 1e-3))))
+    info["time_budget"] = {"estimated_pass_s_at_30GBps_per_link": est_pass_s, "passes": passes, "leg_budget_s": leg_budget_s,
+                           "watchdog_s": stall_seconds, "legs": [n for n, _ in legs]}
+    t_legs = time.perf_counter()
+
+    # Every leg runs under a watchdog: the library's own communicator and its direct exchange have never met a second GPU before an
+    # 8-GPU node runs this (one GPU per build box), and a stalled collective cannot be cancelled from Python.  If a leg does not finish
+    # within stall_seconds, every rank reports what it has (rank 0 prints the JSON line through stall_cb) and leaves with a NON-ZERO
+    # exit code, so that the parent and the driver see the stall.
+    def run_leg(name, mode):
+        nonlocal collector
+        def on_stall():
+            info["stalled_leg"] = name
+            info["own_communicator_error" if mode is not None else "collect_error"] = \
+                f"watchdog: leg {name} did not finish within {stall_seconds:.0f} s"
+            if stall_cb is not None:
+                stall_cb(info)
+            sys.stdout.flush()
+            os._exit(STALL_EXIT_CODE)
+        watchdog = threading.Timer(stall_seconds, on_stall)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if inject_stall_s > 0.0:                                       # test hook: a leg that hangs
+                time.sleep(inject_stall_s)
+            if mode is not None and collector is None:
                 collector = D.PoseCollector(dev, s_comm)
-            except Exception as e:                                         # symmetric: every rank resolves the same library
-                info["own_communicator_error"] = str(e)[:200]
-                break
-        def gather(k):                                                     # on s_comm
-            send = out[k * P * 7:(k + 1) * P * 7]
-            if mode is None:
-                D.all_gather_flat(recv[k & 1], send)
-            else:
-                collector.allgather(send, recv[k & 1], mode=mode, chunk_count=0)
-            total_sum.add_(recv[k & 1].view(torch.int64).sum())            # the sink: checksum of the gathered chunk
-        total_sum.zero_()
-        with torch.cuda.stream(s_comm):
-            gather(0)                                                      # communicator warm-up (outside the timed region)
-        s_comm.synchronize()
-        total_sum.zero_()
-        D.barrier(dev)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(passes):
-            s_comp.wait_stream(s_comm)                                     # a pass rewrites the rows the previous pass's gathers read
-            done = []
-            for k in range(nchunk):
-                with torch.cuda.stream(s_comp):
-                    fuse(k)
-                    e = torch.cuda.Event()
-                    e.record()
-                with torch.cuda.stream(s_comm):
-                    s_comm.wait_event(e)
-                    gather(k)
-                done.append(e)
-        torch.cuda.synchronize(dev)
-        D.barrier(dev)
-        el = D.max_over_ranks(time.perf_counter() - t0, dev) / passes
-        ok = ((int(total_sum.item()) - exp_all * passes) % (1 << 64)) == 0
-        info["collect"][name] = {"pass_ms": el * 1e3, "poses_per_s": world * T * N / el, "recv_GB_per_rank": recv_per_rank / 1e9,
-                                 "recv_GBps_per_rank": recv_per_rank / el / 1e9, "per_link_GBps": recv_per_rank / el / 1e9 / (world - 1),
-                                 "link_frac_of_153": recv_per_rank / el / 1e9 / (world - 1) / XGMI_LINK_GBS,
-                                 "gathered_checksum_equals_sum_of_rank_checksums": bool(ok)}
+            def gather(k):                                                 # on s_comm
+                send = out[k * P * 7:(k + 1) * P * 7]
+                if mode is None:
+                    D.all_gather_flat(recv[k & 1], send)
+                else:
+                    collector.allgather(send, recv[k & 1], mode=mode, chunk_count=0)
+                total_sum.add_(recv[k & 1].view(torch.int64).sum())        # the sink: checksum of the gathered chunk
+            total_sum.zero_()
+            with torch.cuda.stream(s_comm):
+                gather(0)                                                  # communicator warm-up (outside the timed region)
+            s_comm.synchronize()
+            total_sum.zero_()
+            D.barrier(dev)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                s_comp.wait_stream(s_comm)                                 # a pass rewrites the rows the previous pass's gathers read
+                for k in range(nchunk):
+                    with torch.cuda.stream(s_comp):
+                        fuse(k)
+                        e = torch.cuda.Event()
+                        e.record()
+                    with torch.cuda.stream(s_comm):
+                        s_comm.wait_event(e)
+                        gather(k)
+            torch.cuda.synchronize(dev)
+            D.barrier(dev)
+            el = D.max_over_ranks(time.perf_counter() - t0, dev) / passes
+            ok = ((int(total_sum.item()) - exp_all * passes) % (1 << 64)) == 0
+            return {"pass_ms": el * 1e3, "poses_per_s": world * T * N / el, "recv_GB_per_rank": recv_per_rank / 1e9,
+                    "recv_GBps_per_rank": recv_per_rank / el / 1e9, "per_link_GBps": recv_per_rank / el / 1e9 / (world - 1),
+                    "link_frac_of_153": recv_per_rank / el / 1e9 / (world - 1) / XGMI_LINK_GBS, "passes": passes,
+                    "gathered_checksum_equals_sum_of_rank_checksums": bool(ok)}
+        finally:
+            watchdog.cancel()
+
+    for name, mode in legs:
+        if time.perf_counter() - t_legs > leg_budget_s * len(legs):
+            info["collect"][name] = {"skipped": "time budget of the collect legs spent"}
+            continue
+        try:                                                               # one failed leg must not drop the others
+            info["collect"][name] = run_leg(name, mode)
+        except Exception as e:                                             # symmetric over ranks: every rank resolves the same library
+            info["collect"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if mode is not None:
+                info["own_communicator_error"] = info["collect"][name]["error"]
     if collector is not None:
-        collector.close()
-    if watchdog is not None:
-        watchdog.cancel()
+        try:
+            collector.close()
+        except Exception as e:
+            info["collector_close_error"] = str(e)[:200]
     del batch, out, recv
     torch.cuda.empty_cache()
     return info
@@ -369,6 +408,11 @@ def worker(args):
     dev = torch.device("cuda", local)
     os.environ["LOCAL_RANK"] = str(local)
     rank, world, _ = D.init_from_env()
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1 and not rehearsal and backend != "nccl":
+        # one GPU per rank is there: the collect must be RCCL over xGMI, never a CPU-staged gloo rehearsal
+        print(f"bench.py: {world} ranks on {ngpu} GPUs but the process group runs on '{backend}', not nccl (RCCL)", file=sys.stderr)
+        sys.exit(2)
     wl = WORKLOADS[args.workload]
     Bn, N = wl["B"], wl["N"]
     if args.traj_per_gpu:
@@ -383,7 +427,19 @@ def worker(args):
         ctx.set_option(k_, int(v_))
     L = _lib.load()
     base = {"metric": "fused poses/sec (whole node)", "unit": "fused poses/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "backend": backend if world > 1 else "single process (no collective)", "gpus_visible": ngpu}
+    partial = {}                                   # what rank 0 prints if the run-wide deadline fires (N > 1 only)
+    if world > 1:
+        import threading
+
+        def on_deadline():
+            if rank == 0:
+                print(json.dumps(dict(base, **partial, deadline_exceeded=f"{args.deadline_s:.0f} s", value=partial.get("value"))), flush=True)
+            os._exit(STALL_EXIT_CODE)
+        run_deadline = threading.Timer(args.deadline_s, on_deadline)
+        run_deadline.daemon = True
+        run_deadline.start()
 
     # ------------------------------------------------------------------------------------------------ C5 as the headline
     if args.workload == "c5":
@@ -391,7 +447,8 @@ def worker(args):
         def emit_c5(info):
             if rank != 0:
                 return
-            best = min(info["collect"].values(), key=lambda c: c["pass_ms"]) if world > 1 and info.get("collect") else None
+            done = [c for c in info.get("collect", {}).values() if "pass_ms" in c]
+            best = min(done, key=lambda c: c["pass_ms"]) if world > 1 and done else None
             pass_ms = best["pass_ms"] if best else info["compute_only"]["ms"]
             T = info["trajectories_per_gpu"]
             co = info["compute_only"]
@@ -405,9 +462,11 @@ def worker(args):
                                     "kernel_ms": co["ms"] / info["chunks"]},
                           c5=info)
             print(json.dumps(result), flush=True)
-        info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps), stall_cb=emit_c5)
+        info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps), stall_cb=emit_c5,
+                      stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall)
         emit_c5(info)
         if world > 1:
+            run_deadline.cancel()
             torch.distributed.destroy_process_group()
         return
 
@@ -499,6 +558,7 @@ def worker(args):
                              "collect_every_step": {"steps": k2, "ms_per_step": el2 / k2 * 1e3, "poses_per_s": poses_per_step * k2 / el2},
                              "gathered_blocks_equal_rank_checksums": bool(torch.equal(blocks, allsums)),
                              "backend": torch.distributed.get_backend()}
+    partial.update(result)
     # ---- accuracy gate on THIS run: the timed `out` buffers (a sample of the timed batch) against the CPU oracle on the same inputs
     if rank == 0:
         from oracle import oracle as orc
@@ -540,7 +600,8 @@ def worker(args):
                 result["c5"] = info
                 print(json.dumps(result), flush=True)
         try:
-            info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5)
+            info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5,
+                          stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall)
         except Exception as e:                  # sizes are symmetric over ranks, so a failure (e.g. out of memory) is too
             info = {"error": f"{type(e).__name__}: {e}"[:300]}
         result["c5"] = info
@@ -549,6 +610,7 @@ def worker(args):
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        run_deadline.cancel()
         torch.distributed.destroy_process_group()
 
 
@@ -645,6 +707,9 @@ def main():
     ap.add_argument("--chunk-traj", type=int, default=None, help="c5: trajectories per chunk (default 32 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (C3 figures, PCIe-inclusive rate, C1 latency; N>1: the C5 leg)")
+    ap.add_argument("--stall-seconds", type=float, default=240.0, help="N>1: watchdog per collect leg of the C5-shaped run (stall -> partial line, exit code 3)")
+    ap.add_argument("--deadline-s", type=float, default=540.0, help="N>1: run-wide deadline; when it fires rank 0 prints what it has and every rank exits with code 3")
+    ap.add_argument("--inject-stall", type=float, default=0.0, help="test hook: every collect leg of the C5-shaped run sleeps this long first")
     ap.add_argument("--set-option", action="append", default=[], metavar="KEY=VALUE", help="gsf_set_option tuning knob (e.g. duo_kernel=0)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

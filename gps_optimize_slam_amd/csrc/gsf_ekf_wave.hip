@@ -23,8 +23,12 @@ using namespace gsf;
 namespace {
 
 // AXMODE 1: x and y share (P0, Q, R), z does not (checked by the launcher; the default CONFIG) -- see wave_serial_chunks
+#ifndef GSF_BIG_OCC
+#define GSF_BIG_OCC 1
+#endif
+#define GSF_BIG_OCC_EXPR (SMALLBATCH ? 1 : GSF_BIG_OCC)
 template <bool PIPELINE, bool SMALLBATCH, int AXMODE>
-__global__ __launch_bounds__(64) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
+__global__ __launch_bounds__(64, GSF_BIG_OCC_EXPR) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
     wave_serial_body<PIPELINE, false, SMALLBATCH, 1, AXMODE>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
 }

@@ -61,10 +61,12 @@ def test_spawned_ranks_use_loopback_and_fresh_processes(monkeypatch):
         def __init__(self, cmd, env=None, stdout=None):
             seen.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
             self.returncode = 0
-        def communicate(self):
+        def communicate(self, timeout=None):
             return (b'{"ok": 1}\n', None)
         def wait(self, timeout=None):
             return 0
+        def kill(self):
+            pass
     monkeypatch.setattr(bench.subprocess, "Popen", P)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
     assert "torch" not in bench.__dict__
@@ -79,3 +81,40 @@ def test_bench_constants():
     consts = {n.targets[0].id: ast.literal_eval(n.value) for n in tree.body
               if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name) and n.targets[0].id in ("ALG_BYTES_PER_POSE", "HBM_PEAK_GBS")}
     assert consts == {"ALG_BYTES_PER_POSE": 145, "HBM_PEAK_GBS": 8000.0}       # 89 B read + 56 B written; MI355X HBM3E spec
+
+
+def test_spawned_ranks_report_a_stalled_or_failed_rank(monkeypatch):
+    """A rank that stalls (its communicate() / wait() times out) or exits non-zero makes `bench.py --gpus N` exit non-zero; the parent
+    never waits forever, and rank 0's partial line still reaches stdout."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def popen_factory(hang_rank0, rc_other):
+        class P:
+            n = 0
+            def __init__(self, cmd, env=None, stdout=None):
+                self.rank = int(env["RANK"]); self.returncode = None; self.killed = False; self.calls = 0
+            def communicate(self, timeout=None):
+                self.calls += 1
+                if hang_rank0 and self.calls == 1:
+                    raise subprocess.TimeoutExpired("bench", timeout)
+                self.returncode = -9 if self.killed else 0
+                return (b'{"partial": 1}\n', None)
+            def wait(self, timeout=None):
+                self.returncode = rc_other
+                return rc_other
+            def kill(self):
+                self.killed = True
+        return P
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setenv("GSF_BENCH_RANK_TIMEOUT_S", "0.01")
+    monkeypatch.setattr(bench.subprocess, "Popen", popen_factory(True, 0))
+    assert bench.spawn_ranks(2) == 124
+    monkeypatch.setattr(bench.subprocess, "Popen", popen_factory(False, bench.STALL_EXIT_CODE))
+    assert bench.spawn_ranks(2) == bench.STALL_EXIT_CODE
+    monkeypatch.setattr(bench.subprocess, "Popen", popen_factory(False, 0))
+    assert bench.spawn_ranks(2) == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os._exit(0)" not in src and "os._exit(STALL_EXIT_CODE)" in src

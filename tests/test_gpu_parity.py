@@ -527,6 +527,23 @@ def test_bench_two_ranks_self_spawned():
     assert abs(d["value"] - 2 * d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
 
 
+def test_bench_two_ranks_stalled_collect_leg_exits_nonzero():
+    """A collect leg that hangs (injected: every leg sleeps 6 s under a 1.5 s watchdog) ends the run with a NON-ZERO exit code, and
+    rank 0 still prints one JSON line that names the stalled leg."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--inject-stall", "6", "--stall-seconds", "1.5", "--traj-per-gpu", "2048"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode != 0, "a stalled leg must not look like success"
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["c5"]["stalled_leg"] == "torch_all_gather" and "watchdog" in d["c5"]["collect_error"]
+    assert d["backend"] == "gloo" and d["value"] > 0            # the C2 part of the line was measured before the stall
+
+
 # ------------------------------------------------------------------ next-1: time alignment on the device
 def test_time_alignment_kernel_vs_goldens_and_oracle(E, orc, golden):
     g = golden("align_cases.npz")

@@ -14,6 +14,10 @@ __global__ void probe(unsigned* out, int spin)
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     if (VREG == 96) asm volatile("v_mov_b32 v95, 0" ::: "v95");
+    if (VREG == 88) asm volatile("v_mov_b32 v87, 0" ::: "v87");
+    if (VREG == 84) asm volatile("v_mov_b32 v83, 0" ::: "v83");
+    if (VREG == 72) asm volatile("v_mov_b32 v71, 0" ::: "v71");
+    if (VREG == 104) asm volatile("v_mov_b32 v103, 0" ::: "v103");
     if (VREG == 80) asm volatile("v_mov_b32 v79, 0" ::: "v79");
     if (VREG == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
     if (VREG == 64) asm volatile("v_mov_b32 v63, 0" ::: "v63");
@@ -58,7 +62,7 @@ void run(int blocks, int threads)
 int main(int argc, char** argv)
 {
     const int blocks = atoi(argv[1]), threads = atoi(argv[2]);
-    run<64, 0>(blocks, threads); run<80, 0>(blocks, threads); run<96, 0>(blocks, threads); run<96, 23552>(blocks, threads); run<128, 0>(blocks, threads);
-    run<96, 12288>(blocks, threads); run<80, 23552>(blocks, threads);
+    run<64, 0>(blocks, threads); run<72, 0>(blocks, threads); run<80, 0>(blocks, threads); run<84, 0>(blocks, threads); run<88, 0>(blocks, threads);
+    run<96, 0>(blocks, threads); run<104, 0>(blocks, threads); run<128, 0>(blocks, threads); run<80, 23552>(blocks, threads);
     return 0;
 }
