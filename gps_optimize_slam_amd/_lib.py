@@ -103,6 +103,7 @@ SIGNATURES = {
     "gsf_fuse_pipeline_ragged_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_ragged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_time_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
+    "gsf_time_align_loaded_rows_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
     "gsf_time_align_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "gsf_eval_errors_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _vp]),
     "gsf_eval_errors_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _vp, _vp]),

@@ -132,8 +132,10 @@ def fuse_from_geodetic(gb, config=None, out=None):
     check(L.gsf_gps_rows_to_utm_batch_dev(h, _p(gb.gps_llh), _p(gb.gps_offsets), gb.B, _p(utm), _p(zone), _p(south)))
     aligned = torch.empty((gb.B, gb.N, 3), **f)
     valid = torch.empty((gb.B, gb.N), dtype=torch.uint8, device=dev)
-    check(L.gsf_time_align_batch_dev(h, _p(gb.ts), _p(gb.slam_offsets), _p(gb.gps_t), _p(utm), _p(gb.gps_offsets), gb.B, max(2, gb.max_fixes),
-                                     float(g["time_alignment"]["max_gps_gap_threshold"]), _p(aligned), _p(valid), None))
+    # (rows the loader removes -- lat/lon zero or out of range, ref :259-264 -- come out of the geodesy slice as NaN rows and are dropped
+    # when the log is staged: the alignment sees the fixes load_gps_data would have returned)
+    check(L.gsf_time_align_loaded_rows_batch_dev(h, _p(gb.ts), _p(gb.slam_offsets), _p(gb.gps_t), _p(utm), _p(gb.gps_offsets), gb.B, max(2, gb.max_fixes),
+                                                 float(g["time_alignment"]["max_gps_gap_threshold"]), _p(aligned), _p(valid), None))
     out = out or FusedPoses(LAYOUT_TRAJ_MAJOR, gb.B, gb.N, dev)
     R, t, s = torch.empty((gb.B, 9), **f), torch.empty((gb.B, 3), **f), torch.empty((gb.B,), **f)
     check(L.gsf_fuse_pipeline_batch_dev(h, LAYOUT_TRAJ_MAJOR, _p(gb.ts), _p(gb.pos), _p(gb.quat), _p(aligned), _p(valid), C.byref(cfg), gb.B, gb.N,

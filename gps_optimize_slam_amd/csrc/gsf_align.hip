@@ -6,10 +6,15 @@
 //   1. sort by stamp if needed (rank sort, stable by input order) and keep the first of equal stamps (np.unique, :339-346);
 //   2. split at gaps > max_gps_gap_threshold (:348-352); a segment needs >= 2 fixes and stamps increasing by > 1e-9 (:364);
 //   3. >= 4 fixes: not-a-knot cubic spline (scipy interp1d(kind='cubic'), :362/:368) -- the tridiagonal system for the knot
-//      second derivatives is solved by lanes 0..2 (one per component, Thomas algorithm); 2-3 fixes: linear;
+//      second derivatives is solved as three prefix scans over the rows (a Moebius scan for c', an affine scan for d', an affine
+//      scan in reverse for the back substitution; all 64 lanes); 2-3 fixes: linear;
 //   4. every SLAM stamp inside [t0-1e-9, t1+1e-9] (:372-373) is evaluated by its own lane (binary search of the interval);
 //      stamps outside [t0, t1] get NaN like interp1d(bounds_error=False, fill_value=nan); valid = all three finite (:377-379).
 // The clock-offset estimate of :336 is identically 0 and is not computed.
+// NaN stamps sort last (np.argsort), which leaves the last segment without strictly increasing stamps: it is skipped (:364), as in
+// the reference.  drop_masked != 0 (the chain from the geodetic log): fixes whose easting AND northing are NaN -- the mark
+// gsf_gps_rows_to_utm_batch_dev leaves on rows that load_gps_data removes before the projection (:259-264) -- never reach the
+// spline, exactly as if the loader had removed them.
 #include "gsf_internal.hpp"
 #include "gsf_ekf_core.hpp"
 #include "gsf_wave_common.hpp"   // DPP scan stages, lane broadcasts
@@ -26,32 +31,32 @@ constexpr int ALIGN_THREADS = 64;
 template <class StagePtr>
 __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __restrict__ slam_t, const int64_t* __restrict__ slam_off,
                                                 const double* __restrict__ gps_t, const double* __restrict__ gps_p,
-                                                const int64_t* __restrict__ gps_off, double max_gap, int max_g, double* __restrict__ aligned,
-                                                uint8_t* __restrict__ valid, int32_t* __restrict__ status);
+                                                const int64_t* __restrict__ gps_off, double max_gap, int max_g, int drop_masked,
+                                                double* __restrict__ aligned, uint8_t* __restrict__ valid, int32_t* __restrict__ status);
 
 __global__ __launch_bounds__(ALIGN_THREADS) void time_align_kernel(const double* __restrict__ slam_t, const int64_t* __restrict__ slam_off,
                                                                     const double* __restrict__ gps_t, const double* __restrict__ gps_p,
-                                                                    const int64_t* __restrict__ gps_off, double max_gap, int max_g,
+                                                                    const int64_t* __restrict__ gps_off, double max_gap, int max_g, int drop_masked,
                                                                     double* __restrict__ gscratch, double* __restrict__ aligned,
                                                                     uint8_t* __restrict__ valid, int32_t* __restrict__ status)
 {
     extern __shared__ double lds_[];
     typedef __attribute__((address_space(3))) double* LdsPtr;
-    if (gscratch) time_align_body<double*>(gscratch + (size_t)blockIdx.x * 8 * (size_t)max_g, slam_t, slam_off, gps_t, gps_p, gps_off, max_gap, max_g, aligned, valid, status);
-    else time_align_body<LdsPtr>((LdsPtr)lds_, slam_t, slam_off, gps_t, gps_p, gps_off, max_gap, max_g, aligned, valid, status);
+    if (gscratch) time_align_body<double*>(gscratch + (size_t)blockIdx.x * 8 * (size_t)max_g, slam_t, slam_off, gps_t, gps_p, gps_off, max_gap, max_g, drop_masked, aligned, valid, status);
+    else time_align_body<LdsPtr>((LdsPtr)lds_, slam_t, slam_off, gps_t, gps_p, gps_off, max_gap, max_g, drop_masked, aligned, valid, status);
 }
 
 template <class StagePtr>
 __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __restrict__ slam_t, const int64_t* __restrict__ slam_off,
                                                 const double* __restrict__ gps_t, const double* __restrict__ gps_p,
-                                                const int64_t* __restrict__ gps_off, double max_gap, int max_g, double* __restrict__ aligned,
-                                                uint8_t* __restrict__ valid, int32_t* __restrict__ status)
+                                                const int64_t* __restrict__ gps_off, double max_gap, int max_g, int drop_masked,
+                                                double* __restrict__ aligned, uint8_t* __restrict__ valid, int32_t* __restrict__ status)
 {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t s0 = slam_off[b], ns = slam_off[b + 1] - s0;
     const int64_t g0 = gps_off[b];
-    const int ng = (int)(gps_off[b + 1] - g0);
+    int ng = (int)(gps_off[b + 1] - g0);
     const double* st = slam_t + s0;
     double* al = aligned + s0 * 3;
     uint8_t* va = valid + s0;
@@ -63,29 +68,53 @@ __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __re
     StagePtr Y = T + max_g;             // [ng][3] positions
     StagePtr M = Y + 3 * (size_t)max_g; // [ng][3] second derivatives (cubic segments)
     StagePtr W = M + 3 * (size_t)max_g; // [ng] scratch: c' of the Thomas sweep / sort keys
-    // ---- stage + order: rank of fix k = #{j : t_j < t_k or (t_j == t_k and j < k)} (stable argsort, :339)
+    // ---- rows the loader would have removed (drop_masked): the kept fixes' input indices, compacted in input order into M (free
+    // until the spline runs)
+    if (drop_masked) {
+        int kept = 0;
+        for (int k0 = 0; k0 < ng; k0 += ALIGN_THREADS) {
+            const int k = k0 + lane;
+            const bool keep = k < ng && !(isnan(gps_p[(g0 + k) * 3]) && isnan(gps_p[(g0 + k) * 3 + 1]));
+            const unsigned long long m = __ballot(keep);
+            if (keep) M[kept + __popcll(m & ((1ull << lane) - 1ull))] = (double)k;
+            kept += __popcll(m);
+        }
+        __syncthreads();
+        ng = kept;
+        if (ng < 2) return;                                              // :332-334 on the rows that survive the loader
+    }
+#define GSF_AL_SRC(k) (g0 + (drop_masked ? (int)M[k] : (k)))
+    // ---- stage + order: rank of fix k = #{j : t_j < t_k or (t_j == t_k and j < k)} (stable argsort, :339); NaN stamps rank last
     bool sorted = true;
     for (int k = lane; k < ng; k += ALIGN_THREADS) {
-        const double tk = gps_t[g0 + k];
+        const double tk = gps_t[GSF_AL_SRC(k)];
         W[k] = tk;
-        if (k > 0 && !(gps_t[g0 + k - 1] < tk)) sorted = false;
+        if (k > 0 && !(gps_t[GSF_AL_SRC(k - 1)] < tk)) sorted = false;
     }
     __syncthreads();
     sorted = (__ballot(!sorted) == 0ull);
     if (sorted) {
         for (int k = lane; k < ng; k += ALIGN_THREADS) {
+            const int64_t src = GSF_AL_SRC(k);
             T[k] = W[k];
-            Y[k * 3] = gps_p[(g0 + k) * 3]; Y[k * 3 + 1] = gps_p[(g0 + k) * 3 + 1]; Y[k * 3 + 2] = gps_p[(g0 + k) * 3 + 2];
+            Y[k * 3] = gps_p[src * 3]; Y[k * 3 + 1] = gps_p[src * 3 + 1]; Y[k * 3 + 2] = gps_p[src * 3 + 2];
         }
     } else {
         for (int k = lane; k < ng; k += ALIGN_THREADS) {
             const double tk = W[k];
+            const bool nk = isnan(tk);
             int rank = 0;
-            for (int j = 0; j < ng; ++j) { const double tj = W[j]; rank += (tj < tk || (tj == tk && j < k)) ? 1 : 0; }
+            for (int j = 0; j < ng; ++j) {
+                const double tj = W[j];
+                const bool nj = isnan(tj);
+                rank += (tj < tk || (!nj && nk) || ((tj == tk || (nj && nk)) && j < k)) ? 1 : 0;
+            }
+            const int64_t src = GSF_AL_SRC(k);
             T[rank] = tk;
-            Y[rank * 3] = gps_p[(g0 + k) * 3]; Y[rank * 3 + 1] = gps_p[(g0 + k) * 3 + 1]; Y[rank * 3 + 2] = gps_p[(g0 + k) * 3 + 2];
+            Y[rank * 3] = gps_p[src * 3]; Y[rank * 3 + 1] = gps_p[src * 3 + 1]; Y[rank * 3 + 2] = gps_p[src * 3 + 2];
         }
     }
+#undef GSF_AL_SRC
     __syncthreads();
     // ---- np.unique(return_index=True): keep the first fix of every run of equal stamps (:341-346).  Compaction in place by
     // one lane -- duplicates are rare and ng is a few hundred.
@@ -228,7 +257,7 @@ __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __re
                         }
                     }
                     al[i * 3] = v0; al[i * 3 + 1] = v1; al[i * 3 + 2] = v2;                       // :375
-                    va[i] = !(isnan(v0) || isnan(v1) || isnan(v2)) ? 1 : 0;                         // :377-379
+                    if (!(isnan(v0) || isnan(v1) || isnan(v2))) va[i] = 1;                          // :377-379 (only ever set, never cleared)
                 }
                 __syncthreads();
             }
@@ -241,9 +270,9 @@ __device__ __forceinline__ void time_align_body(StagePtr lds, const double* __re
 
 extern "C" {
 
-int gsf_time_align_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
+static int time_align_launch(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
                              const int64_t* gps_offsets, int64_t B, int32_t max_gps_per_trajectory, double max_gps_gap_threshold,
-                             double* aligned, uint8_t* valid, int32_t* status)
+                             int drop_masked, double* aligned, uint8_t* valid, int32_t* status)
 {
     GSF_REQUIRE(ctx && slam_offsets && gps_offsets && aligned && valid, "NULL argument");
     GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
@@ -260,9 +289,23 @@ int gsf_time_align_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* 
         GSF_HIP(hipFuncSetAttribute((const void*)time_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL(time_align_kernel, dim3((unsigned)B), dim3(ALIGN_THREADS), lds, ctx->stream, slam_t, slam_offsets, gps_t, gps_p, gps_offsets,
-                       max_gps_gap_threshold, (int)max_gps_per_trajectory, gscratch, aligned, valid, status);
+                       max_gps_gap_threshold, (int)max_gps_per_trajectory, drop_masked, gscratch, aligned, valid, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
+}
+
+int gsf_time_align_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
+                             const int64_t* gps_offsets, int64_t B, int32_t max_gps_per_trajectory, double max_gps_gap_threshold,
+                             double* aligned, uint8_t* valid, int32_t* status)
+{
+    return time_align_launch(ctx, slam_t, slam_offsets, gps_t, gps_p, gps_offsets, B, max_gps_per_trajectory, max_gps_gap_threshold, 0, aligned, valid, status);
+}
+
+int gsf_time_align_loaded_rows_batch_dev(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,
+                                         const int64_t* gps_offsets, int64_t B, int32_t max_gps_per_trajectory, double max_gps_gap_threshold,
+                                         double* aligned, uint8_t* valid, int32_t* status)
+{
+    return time_align_launch(ctx, slam_t, slam_offsets, gps_t, gps_p, gps_offsets, B, max_gps_per_trajectory, max_gps_gap_threshold, 1, aligned, valid, status);
 }
 
 int gsf_time_align_batch(gsf_ctx* ctx, const double* slam_t, const int64_t* slam_offsets, const double* gps_t, const double* gps_p,

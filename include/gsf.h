@@ -300,6 +300,13 @@ GSF_API int gsf_time_align_batch_dev(gsf_ctx *ctx, const double *slam_t, const i
 GSF_API int gsf_time_align_batch(gsf_ctx *ctx, const double *slam_t, const int64_t *slam_offsets, const double *gps_t, const double *gps_p,
                                  const int64_t *gps_offsets, int64_t B, double max_gps_gap_threshold, double *aligned, uint8_t *valid,
                                  int32_t *status);
+/* The same for a GNSS log that comes straight from gsf_gps_rows_to_utm_batch_dev: rows whose easting AND northing are NaN are the
+   rows load_gps_data removes before the projection (EKFGPSSLAM.py:259-264: lat/lon zero or out of range); they are dropped when the
+   log is staged, so the alignment sees exactly the fixes the reference's loader hands to dynamic_time_alignment. */
+GSF_API int gsf_time_align_loaded_rows_batch_dev(gsf_ctx *ctx, const double *slam_t, const int64_t *slam_offsets, const double *gps_t,
+                                                 const double *gps_p, const int64_t *gps_offsets, int64_t B,
+                                                 int32_t max_gps_per_trajectory, double max_gps_gap_threshold, double *aligned,
+                                                 uint8_t *valid, int32_t *status);
 
 /* ---- error evaluation (main_process_gui step 6, EKFGPSSLAM.py:1013-1033) -------------------- */
 /* B trajectories x N poses, trajectory-major.  For every index with valid finite aligned GNSS and ts > ts[0] + skip_seconds:

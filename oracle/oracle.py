@@ -140,6 +140,12 @@ def quaternion_nlerp(q1, q2, w):
     return out
 
 
+# ---- EKFGPSSLAM.py:259 (load_gps_data's validity mask: rows outside it are removed before the projection, :260-264) ----
+def valid_latlon_mask(lats, lons):
+    lats, lons = np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64)
+    return (np.abs(lats) <= 90) & (np.abs(lons) <= 180) & (lats != 0) & (lons != 0)
+
+
 # ---- EKFGPSSLAM.py:127-134, :266-271, :291-296 ------------------------------
 def auto_utm_projection(lons, lats):
     lons, lats = _a(lons).ravel(), _a(lats).ravel()

@@ -940,6 +940,54 @@ def test_device_chain_from_geodetic_log_vs_oracle(B, orc):
     np.testing.assert_array_equal(part.gps_llh.cpu().numpy(), llh[o32:offs[64]])
 
 
+def test_device_chain_drops_the_rows_the_loader_removes(B, orc):
+    """A geodetic log with rows load_gps_data throws away before the projection (lat or lon zero / out of range, ref :259-264): the
+    device chain must align on the remaining fixes only -- checked against the oracle chained on the filtered log, the way the
+    reference's loader hands it to dynamic_time_alignment.  (A NaN row fed to the spline would wipe out the whole cubic segment.)"""
+    import torch
+    nb, N = 48, 271
+    gb = B.GeodeticBatch.synthetic(nb, N, seed=11)
+    offs = gb.gps_offsets.cpu().numpy()
+    llh = gb.gps_llh.cpu().numpy().copy()
+    rng = np.random.default_rng(4)
+    bad_rows = []
+    for b in range(nb):
+        lo, hi = offs[b], offs[b + 1]
+        if b % 4 == 3:
+            continue                                                       # some logs stay clean
+        for k in rng.choice(np.arange(lo + 2, hi - 2), size=3, replace=False):
+            kind = rng.integers(0, 4)
+            if kind == 0: llh[k, 0] = 0.0                                  # lat == 0
+            elif kind == 1: llh[k, 1] = 0.0                                # lon == 0
+            elif kind == 2: llh[k, 0] = 97.5                               # |lat| > 90
+            else: llh[k, 1] = -200.0                                       # |lon| > 180
+            bad_rows.append(k)
+    gb.gps_llh = torch.as_tensor(llh).cuda()
+    out, R, t, s, aux = B.fuse_from_geodetic(gb)
+    p, q, st = out.host_traj_major()
+    gt = gb.gps_t.cpu().numpy()
+    ts, pos, quat = gb.ts.cpu().numpy(), gb.pos.cpu().numpy(), gb.quat.cpu().numpy()
+    utm, aligned, valid = aux["utm_rows"].cpu().numpy(), aux["aligned"].cpu().numpy(), aux["valid"].cpu().numpy()
+    assert np.isnan(utm[bad_rows, 0]).all() and np.isnan(utm[bad_rows, 1]).all()          # the geodesy slice marks them
+    al_ref = np.full((nb, N, 3), np.nan); va_ref = np.zeros((nb, N), dtype=bool)
+    for b in range(nb):
+        lo, hi = offs[b], offs[b + 1]
+        keep = orc.valid_latlon_mask(llh[lo:hi, 0], llh[lo:hi, 1])
+        assert keep.sum() == (hi - lo) - sum(lo <= k < hi for k in bad_rows)
+        la, lo_, alt, tt = llh[lo:hi, 0][keep], llh[lo:hi, 1][keep], llh[lo:hi, 2][keep], gt[lo:hi][keep]
+        zo, hemi = orc.auto_utm_projection(lo_, la)
+        e, n = orc.utm_forward(la, lo_, zo, "south" in hemi)
+        al_ref[b], va_ref[b] = orc.dynamic_time_alignment(ts[b], tt, np.column_stack((e, n, alt)), 500, 5.0)
+        np.testing.assert_array_equal(valid[b].astype(bool), va_ref[b], err_msg=f"log {b}")
+        np.testing.assert_allclose(aligned[b][va_ref[b]], al_ref[b][va_ref[b]], atol=1e-8, rtol=0)
+    assert va_ref.mean() > 0.8                                             # the bad rows did not take their segments with them
+    po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(ts, pos, quat, al_ref, va_ref.astype(np.uint8))
+    ok = np.isfinite(po).all(axis=(1, 2))
+    assert ok.sum() >= nb - 2
+    assert np.abs(p[ok] - po[ok]).max() < POS_TOL and np.abs(q[ok] - qo[ok]).max() < 1e-8
+    np.testing.assert_array_equal(st[ok] & 0xff, sto[ok] & 0xff)
+
+
 def test_device_mt19937_choice_matches_numpy(B):
     """np.random.choice(n, k, replace=False) of NumPy's legacy generator reproduced on the device: the same sample sets trial by
     trial AND the same generator state afterwards (the next NumPy draw continues the stream), for seeded streams and for a state
