@@ -56,12 +56,34 @@ class TrajectoryBatch:
         self.init_pos, self.init_quat = torch.empty((B, 3), **f), torch.empty((B, 4), **f)
 
     @classmethod
-    def synthetic(cls, B, N, layout=LAYOUT_TIME_MAJOR, seed=20250523, traj0=0, device="cuda"):
-        """Deterministic KITTI-04-shaped batch generated on the device (gsf_synth_batch_dev)."""
+    def synthetic(cls, B, N, layout=LAYOUT_TIME_MAJOR, seed=20250523, traj0=0, device="cuda", variant=0):
+        """Deterministic KITTI-04-shaped batch generated on the device (gsf_synth_batch_dev).  variant 0: white 2 cm noise on
+        the SLAM positions (the default workload); variant 1: SURVEY 8d to the letter -- a random-walk drift of 2 cm per pose and the
+        sharp-turn burst on 5 % of the tracks."""
         b = cls(layout, B, N, device)
-        check(_lib.load().gsf_synth_batch_dev(context().handle, b.layout, C.c_uint64(seed), int(traj0), b.B, b.N, _p(b.ts), _p(b.pos),
-                                              _p(b.quat), _p(b.gps), _p(b.valid), _p(b.init_pos), _p(b.init_quat)))
+        ctx = context()
+        ctx.set_option("synth_variant", int(variant))
+        try:
+            check(_lib.load().gsf_synth_batch_dev(ctx.handle, b.layout, C.c_uint64(seed), int(traj0), b.B, b.N, _p(b.ts), _p(b.pos),
+                                                  _p(b.quat), _p(b.gps), _p(b.valid), _p(b.init_pos), _p(b.init_quat)))
+        finally:
+            ctx.set_option("synth_variant", 0)
         return b
+
+    @classmethod
+    def replicated(cls, ts, pos, quat, gps, valid, B, gnss_sigma=0.45, seed=0, layout=LAYOUT_TRAJ_MAJOR, device="cuda"):
+        """B copies of ONE real track (ts (N,), pos (N,3), quat (N,4), time-aligned gps (N,3) with NaN where invalid, valid (N,)) with
+        independent white GNSS noise of gnss_sigma metres per copy (copy 0 keeps the fixes as they are) -- e.g. the bundled KITTI-04
+        track of config C1 as a batch.  init_pos / init_quat are pose 0 of the track (placeholders: the fused pipeline fits its own)."""
+        import numpy as np
+        ts, pos, quat, gps = (np.asarray(a, dtype=np.float64) for a in (ts, pos, quat, gps))
+        N = ts.shape[0]
+        rng = np.random.default_rng(seed)
+        g = np.repeat(gps[None], B, axis=0)
+        noise = rng.normal(scale=gnss_sigma, size=(B, N, 3)); noise[0] = 0.0
+        g = g + noise
+        rep = lambda a: np.repeat(np.asarray(a)[None], B, axis=0)
+        return cls.from_host(rep(ts), rep(pos), rep(quat), g, rep(np.asarray(valid).astype(np.uint8)), rep(pos[0]), rep(quat[0]), layout=layout, device=device)
 
     @classmethod
     def from_host(cls, ts, pos, quat, gps, valid, init_pos, init_quat, layout=LAYOUT_TRAJ_MAJOR, device="cuda"):

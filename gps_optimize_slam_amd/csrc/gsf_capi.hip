@@ -163,7 +163,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
-    c->ekf_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
+    c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
     // kernel-choice override for A/B runs of the whole test suite (the same meaning as gsf_set_option "block_kernel")
     if (const char* e = getenv("GSF_BLOCK_KERNEL")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->block_kernel = v; }
     if (owns) {
@@ -205,6 +205,10 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
 {
     GSF_REQUIRE(ctx && key, "NULL argument");
     if (strcmp(key, "ekf_variant") == 0) { ctx->ekf_variant = (int)value; return GSF_OK; }
+    if (strcmp(key, "synth_variant") == 0) {
+        if (value < 0 || value > 1) { set_error("gsf_set_option: synth_variant must be 0 (white SLAM noise) or 1 (random-walk drift, SURVEY 8d)"); return GSF_ERR_INVALID_ARG; }
+        ctx->synth_variant = (int)value; return GSF_OK;
+    }
     if (strcmp(key, "block_kernel") == 0) {
         if (value < -1 || value > 1) { set_error("gsf_set_option: block_kernel must be -1 (automatic), 0 (never) or 1 (whenever it applies)"); return GSF_ERR_INVALID_ARG; }
         ctx->block_kernel = (int)value; return GSF_OK;

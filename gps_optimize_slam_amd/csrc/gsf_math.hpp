@@ -373,7 +373,7 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
 }
 
 // status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
-enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8 };
+enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8, SIM3_FLAG_SVD_FALLBACK = 16 };
 
 // the SVD route of the closed form's rotation, ref :439-444: R = Vt.T @ U.T with the reflection fix, tr = S0 + S1 + S2 det(R)
 GSF_HD void umeyama_rotation_svd(const double* H, double* R, double& tr)
@@ -418,7 +418,9 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
     for (int i = 0; i < 9; ++i) finite = finite && (fabs(H[i]) < INFINITY);   // NaN/inf -> LinAlgError -> None (:452)
     if (!finite) return SIM3_NONE;
     double tr = 0.0;
+    int32_t flags = SIM3_OK;
     if (!(POLAR && umeyama_rotation_polar<COLD_SVD>(H, R, tr))) {                        // tr: S0+S1+S2 (det(R) = 1 to rounding, Q12)
+        if (POLAR) flags |= SIM3_FLAG_SVD_FALLBACK;                                      // informational: the polar route declined this H
         if (COLD_SVD) {
             double Hm[9]; SvdRot o;
 #pragma unroll
@@ -433,7 +435,6 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
     }
     const double rcp_n = fast_rcp(n);                                          // n >= 3
     double var_src = ssq * rcp_n;                                              // (:443)
-    int32_t flags = SIM3_OK;
     if (var_src < 1e-12) { scale = 1.0; flags |= SIM3_FLAG_VAR0; }             // (:445-447)
     else {
         scale = tr * fast_rcp(n * var_src);                                    // (:449)  n var_src >= 3e-12: normal range

@@ -131,8 +131,11 @@ __device__ __forceinline__ double nrm(uint64_t seed, uint64_t j, uint64_t i, uin
 
 constexpr uint64_t TRAJ = 0xFFFFFFFFull;   // "step" slot used for per-trajectory draws
 
+// variant 0: white 2 cm noise on the SLAM positions, the sharp-turn burst on a quarter of the mid-track outages (2.5 % of the tracks);
+// variant 1 (SURVEY 8d to the letter): the SLAM error is a random-walk DRIFT of 2 cm per pose, and 5 % of ALL tracks get the burst
+// (inside the outage where there is one, else from mid-track on)
 template <int LAYOUT>
-__global__ __launch_bounds__(64) void synth_kernel(uint64_t seed, int64_t traj0, int64_t B, int64_t N, double* __restrict__ ts,
+__global__ __launch_bounds__(64) void synth_kernel(int variant, uint64_t seed, int64_t traj0, int64_t B, int64_t N, double* __restrict__ ts,
                                                    double* __restrict__ pos, double* __restrict__ quat, double* __restrict__ gps,
                                                    uint8_t* __restrict__ valid, double* __restrict__ init_pos, double* __restrict__ init_quat)
 {
@@ -158,8 +161,12 @@ __global__ __launch_bounds__(64) void synth_kernel(uint64_t seed, int64_t traj0,
         burst = u01(seed, j, TRAJ, 13) < 0.25; bstart = o0 + L / 4;
     } else if (kind < 0.12) { o0 = 0; o1 = 10 + (int64_t)(u01(seed, j, TRAJ, 11) * 31.0); if (o1 > N / 2) o1 = N / 2; }
     else if (kind < 0.14) { int64_t K = 10 + (int64_t)(u01(seed, j, TRAJ, 11) * 31.0); if (K > N / 2) K = N / 2; o0 = N - K; o1 = N; }
+    if (variant == 1) {
+        burst = u01(seed, j, TRAJ, 13) < 0.05;
+        if (!(kind < 0.10)) bstart = N / 2;
+    }
     double t_prev = 0.0, t_burst = 0.0;
-    Vec3 p{ 0.0, 0.0, 0.0 };
+    Vec3 p{ 0.0, 0.0, 0.0 }, drift{ 0.0, 0.0, 0.0 };
     for (int64_t i = 0; i < N; ++i) {
         const double t = (i == 0) ? 0.0 : (double)i * 0.10411 + uni(-0.002, 0.002, seed, j, (uint64_t)i, 0);
         const double tau = t / T;
@@ -174,8 +181,9 @@ __global__ __launch_bounds__(64) void synth_kernel(uint64_t seed, int64_t traj0,
         t_prev = t;
         Quat qy, qz; quat_unit(Quat{ 0.0, u, 0.0, 1.0 }, qy); quat_unit(Quat{ 0.0, 0.0, v, 1.0 }, qz);
         const Quat q = quat_mul(qz, qy);
-        const Vec3 ps{ p.x / scale + 0.02 * nrm(seed, j, (uint64_t)i, 1), p.y / scale + 0.02 * nrm(seed, j, (uint64_t)i, 2),
-                       p.z / scale + 0.02 * nrm(seed, j, (uint64_t)i, 3) };
+        Vec3 e{ 0.02 * nrm(seed, j, (uint64_t)i, 1), 0.02 * nrm(seed, j, (uint64_t)i, 2), 0.02 * nrm(seed, j, (uint64_t)i, 3) };
+        if (variant == 1) { drift.x += e.x; drift.y += e.y; drift.z += e.z; e = drift; }
+        const Vec3 ps{ p.x / scale + e.x, p.y / scale + e.y, p.z / scale + e.z };
         const Vec3 rg = quat_rotate(qg, p);
         const bool ok = !(i >= o0 && i < o1);
         const Vec3 z{ ok ? rg.x + tg.x + 0.45 * nrm(seed, j, (uint64_t)i, 4) : NAN, ok ? rg.y + tg.y + 0.45 * nrm(seed, j, (uint64_t)i, 5) : NAN,
@@ -302,9 +310,9 @@ int gsf_synth_batch_dev(gsf_ctx* ctx, int32_t layout, uint64_t seed, int64_t tra
     GSF_HIP(hipSetDevice(ctx->device));
     const dim3 block(64), grid((unsigned)((B + 63) / 64));
     if (layout == GSF_LAYOUT_TIME_MAJOR)
-        hipLaunchKernelGGL(synth_kernel<GSF_LAYOUT_TIME_MAJOR>, grid, block, 0, ctx->stream, seed, traj0, B, N, ts, pos, quat, gps, valid, init_pos, init_quat);
+        hipLaunchKernelGGL(synth_kernel<GSF_LAYOUT_TIME_MAJOR>, grid, block, 0, ctx->stream, ctx->synth_variant, seed, traj0, B, N, ts, pos, quat, gps, valid, init_pos, init_quat);
     else
-        hipLaunchKernelGGL(synth_kernel<GSF_LAYOUT_TRAJ_MAJOR>, grid, block, 0, ctx->stream, seed, traj0, B, N, ts, pos, quat, gps, valid, init_pos, init_quat);
+        hipLaunchKernelGGL(synth_kernel<GSF_LAYOUT_TRAJ_MAJOR>, grid, block, 0, ctx->stream, ctx->synth_variant, seed, traj0, B, N, ts, pos, quat, gps, valid, init_pos, init_quat);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -596,11 +596,33 @@ def benchmark_c1(repeats=20, golden_dir=None):
     return out
 
 
-def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):
-    """Steps 1-5 (+7: save) of main_process_gui without tk dialogs (ref :940-1104).  Returns a dict of all stages."""
+def evaluate_against(slam, trajectories, gps_data, config=None, skip_seconds=5.0):
+    """Step 6 of main_process_gui for one GNSS data set (ref :1013-1033 for the primary GPS, :1035-1062 for the ground truth): time
+    alignment of `gps_data` to the SLAM stamps (:1014 / :1037), then the reference's error metric of every trajectory in
+    `trajectories` (label -> (N, 3)) against the aligned fixes after the first `skip_seconds`.  Returns {'aligned', 'valid',
+    'points', label: evaluate_trajectory_errors(...)}."""
+    config = config or CONFIG
+    aligned, valid = dynamic_time_alignment(slam, gps_data, config["time_alignment"])
+    out = {"aligned": aligned, "valid": valid}
+    for label, tr in trajectories.items():
+        out[label] = evaluate_trajectory_errors(slam["timestamps"], tr, aligned, valid, skip_seconds)
+    out["points"] = int(next(iter(out[k]["count"] for k in trajectories), 0)) if trajectories else 0
+    return out
+
+
+def run_fusion(slam_path, gps_path, out_path_utm=None, config=None, gt_gps_path=None):
+    """Steps 1-7 of main_process_gui without tk dialogs (ref :940-1104).  gt_gps_path: the optional second GNSS file the reference
+    asks for (:949-953), loaded with CONFIG['ground_truth_gps_filtering'] (:964) and used as ground truth in step 6.  Returns a dict of
+    all stages; step 6 is 'errors' = {'primary': {...}, 'ground_truth': {...} or None} with the rows of :1027 / :1049 (raw SLAM,
+    Sim3, EKF) and 'plot_error_ref' = which of the two the reference's plots show (:1064-1075)."""
     config = copy.deepcopy(config or CONFIG)
     slam = load_slam_trajectory(slam_path)                                                       # step 1
     gps = load_gps_data(gps_path, data_label="primary GPS", filter_config_override=config["gps_filtering_ransac"])
+    gt = None
+    if gt_gps_path:
+        gt = load_gps_data(gt_gps_path, data_label="GNSS ground truth", filter_config_override=config["ground_truth_gps_filtering"])   # :964
+        if len(gt["positions"]) < 2:                                                             # :966: not used
+            gt = None
     if len(slam["positions"]) == 0 or len(gps["positions"]) < 2:
         raise ValueError("empty SLAM data or fewer than 2 GPS points")
     aligned, valid = dynamic_time_alignment(slam, gps, config["time_alignment"])                 # step 2
@@ -612,6 +634,16 @@ def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):
         raise RuntimeError("global Sim3 transform failed")                                       # ref :1003
     sim3_pos, sim3_quat = transform_trajectory(slam["positions"], slam["quaternions"], R, t, s)  # step 4
     pos, quat = apply_ekf_correction(slam, gps, sim3_pos, sim3_quat, config)                     # step 5
+    # step 6 (ref :1013-1075): raw SLAM / Sim3 / EKF rows against the primary GPS and, if given, the ground truth
+    tracks = {"raw_slam": slam["positions"], "sim3": sim3_pos, "ekf": pos}
+    e_primary = evaluate_against(slam, tracks, gps, config)
+    e_gt = evaluate_against(slam, tracks, gt, config) if gt is not None else None
+    if e_gt is not None and e_gt["ekf"]["count"] > 0:                                            # :1064-1069
+        plot_ref = "ground_truth"
+    elif e_primary["ekf"]["count"] > 0:                                                          # :1070-1074
+        plot_ref = "primary"
+    else:
+        plot_ref = None                                                                          # :1075
     if out_path_utm:                                                                             # step 7
         save_tum_utm(out_path_utm, slam["timestamps"], pos, quat)
         wgs = utm_to_wgs84(pos, gps["projector"])
@@ -619,7 +651,7 @@ def run_fusion(slam_path, gps_path, out_path_utm=None, config=None):
         if out_wgs == out_path_utm:
             out_wgs = out_path_utm.replace(".txt", "_wgs84.txt") if ".txt" in out_path_utm else out_path_utm + "_wgs84.txt"
         save_tum_wgs84(out_wgs, slam["timestamps"], wgs, quat)
-    err_sim3 = evaluate_trajectory_errors(slam["timestamps"], sim3_pos, aligned, valid)          # step 6 (vs the primary GPS)
-    err_ekf = evaluate_trajectory_errors(slam["timestamps"], pos, aligned, valid)
-    return {"slam": slam, "gps": gps, "aligned": aligned, "valid": valid, "sim3_idx": idx, "R": R, "t": t, "s": s,
-            "sim3_pos": sim3_pos, "sim3_quat": sim3_quat, "pos": pos, "quat": quat, "err_sim3": err_sim3, "err_ekf": err_ekf}
+    return {"slam": slam, "gps": gps, "ground_truth_gps": gt, "aligned": aligned, "valid": valid, "sim3_idx": idx, "R": R, "t": t, "s": s,
+            "sim3_pos": sim3_pos, "sim3_quat": sim3_quat, "pos": pos, "quat": quat,
+            "errors": {"primary": e_primary, "ground_truth": e_gt}, "plot_error_ref": plot_ref,
+            "err_sim3": e_primary["sim3"], "err_ekf": e_primary["ekf"]}

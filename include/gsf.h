@@ -69,6 +69,9 @@ typedef struct {
 #define GSF_SIM3_FLAG_VAR0 2          /* var_src < 1e-12 -> scale := 1   (EKFGPSSLAM.py:445-447) */
 #define GSF_SIM3_FLAG_SMALL_SCALE 4   /* scale <= 1e-6  -> scale := 1   (EKFGPSSLAM.py:450) */
 #define GSF_SIM3_FLAG_BAD_INDEX 8     /* a caller-fed sample set named a row outside [0, n): that trial was skipped */
+#define GSF_SIM3_FLAG_SVD_FALLBACK 16 /* informational (fused pipeline): the closed form's rotation came from the Jacobi SVD because the
+                                         polar iteration declined this cross-covariance (rank-deficient / weakly separated reflection);
+                                         same result to ~1e-14, only slower */
 
 /* status bits of a fused trajectory */
 #define GSF_ST_HAD_OUTAGE 1

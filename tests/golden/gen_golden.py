@@ -582,7 +582,55 @@ def gen_filter_cases():
     save("gpsfilter_cases.npz", **out)
 
 
+# --------------------------------------------------------------------------
+def gen_step6_with_ground_truth(slam):
+    """Step 6 of main_process_gui with the optional second GNSS file (ref :949-953, :963-966, :1013-1075): primary GPS =
+    combined_output.txt (the C1 'combined' case above, same seed), ground truth = 5.1Kitti04gps through load_gps_data's path with
+    CONFIG['ground_truth_gps_filtering'].  The metric of :1027-1033 / :1049-1056 for the raw SLAM, the Sim3 and the EKF track against
+    both, and which of the two the plot would use (:1064-1075).  (The two bundled files are read per Q1 and land in different UTM
+    zones: the numbers are huge and meaningless as accuracy, which makes them a good arithmetic check.)"""
+    from scipy.spatial import distance
+    c1 = np.load(os.path.join(HERE, "c1_combined.npz"))
+    gps = {"timestamps": c1["gps_t"], "positions": c1["gps_p"]}
+    sim3_pos, ekf_pos = c1["sim3_pos"], c1["ekf_pos"]
+    raw = np.loadtxt(f"{REF}/5.1Kitti04gps", delimiter=" ")
+    t_raw, lat, lon, alt = raw[:, 0], raw[:, 1], raw[:, 2], raw[:, 3]        # ref :258 (Q1)
+    m = (np.abs(lat) <= 90) & (np.abs(lon) <= 180) & (lat != 0) & (lon != 0)  # ref :259
+    t_raw, lat, lon, alt = t_raw[m], lat[m], lon[m], alt[m]
+    zone, hemi = ref.auto_utm_projection(lon, lat)
+    e, n = orc.utm_forward(lat, lon, zone, "south" in hemi)                   # stands in for ref :270
+    np.random.seed(0)
+    with quiet():
+        gt_t, gt_p = ref.filter_gps_outliers_ransac(t_raw, np.column_stack((e, n, alt)), ref.CONFIG["ground_truth_gps_filtering"])  # ref :964
+        al_p, va_p = ref.dynamic_time_alignment(slam, gps, ref.CONFIG["time_alignment"])                       # ref :1014
+        al_g, va_g = ref.dynamic_time_alignment(slam, {"timestamps": gt_t, "positions": gt_p}, ref.CONFIG["time_alignment"])   # ref :1037
+    out = dict(gt_t_raw=t_raw, gt_lat=lat, gt_lon=lon, gt_alt=alt, gt_zone=np.int32(zone), gt_south=np.int32("south" in hemi),
+               gt_t=gt_t, gt_p=gt_p, aligned_primary=al_p, valid_primary=va_p, aligned_gt=al_g, valid_gt=va_g)
+    ekf_err = {}
+    for tag, al, va in (("primary", al_p, va_p), ("gt", al_g, va_g)):
+        vi = np.where(va)[0]
+        post = vi[slam["timestamps"][vi] > slam["timestamps"][0] + 5.0]      # ref :1020-1023 / :1041-1044
+        cand = al[post]
+        rows = []
+        for tr in (slam["positions"], sim3_pos, ekf_pos):                     # ref :1027 / :1049: raw SLAM, Sim3, EKF
+            d = distance.cdist(tr[post], cand, "euclidean").min(axis=1)       # ref :1030-1031
+            rows.append([len(d), d.mean(), np.median(d), np.sqrt((d ** 2).mean())])
+            last = d
+        ekf_err[tag] = last
+        out[f"err_{tag}"] = np.array(rows)                                    # rows: raw SLAM, Sim3, EKF; cols: count, mean, median, rmse
+        out[f"post_idx_{tag}"] = post.astype(np.int32)
+    # ref :1064-1075: ground truth first, then the primary GPS
+    out["plot_ref"] = np.array("gt" if len(gt_p) >= 2 and len(ekf_err["gt"]) > 0 else ("primary" if len(ekf_err["primary"]) > 0 else "none"))
+    save("step6_gt.npz", **out)
+    print(f"   step 6: GT zone {zone}{hemi!r}, {len(out['post_idx_gt'])} GT points / {len(out['post_idx_primary'])} primary points, plot ref {out['plot_ref']}")
+
+
 if __name__ == "__main__":
+    if "--only-step6" in sys.argv:
+        with quiet():
+            slam_ = ref.load_slam_trajectory(f"{REF}/yolotum04.txt")
+        gen_step6_with_ground_truth(slam_)
+        sys.exit(0)
     if "--only-filter" in sys.argv:                  # later additions regenerate alone: the other files stay byte-identical
         gen_filter_cases()
         sys.exit(0)
@@ -594,3 +642,4 @@ if __name__ == "__main__":
     gen_helper_cases()
     gen_align_cases(slam)
     gen_filter_cases()
+    gen_step6_with_ground_truth(slam)
