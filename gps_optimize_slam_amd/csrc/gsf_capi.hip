@@ -312,7 +312,7 @@ int gsf_sim3_ransac_mt_batch(gsf_ctx* ctx, const double* src, const double* dst,
                              int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
 {
     GSF_REQUIRE(ctx && offsets && B >= 0 && B <= 0x7fffffff && mt_state && R && t && s && status && inlier_mask && n_inliers, "bad arguments");
-    GSF_REQUIRE(trials >= 0 && trials <= (1 << 20) && min_samples >= 1 && min_samples <= 8, "bad trials / min_samples (1..8)");
+    GSF_REQUIRE(trials >= 0 && trials <= (1 << 20) && min_samples >= 1 && min_samples <= 64, "bad trials / min_samples (1..64: the device sampler traces up to 64 positions per trial)");
     if (B == 0) return GSF_OK;
     const int64_t total = offsets[B];
     GSF_REQUIRE(total >= 0 && (total == 0 || (src && dst)), "bad offsets / NULL points");

@@ -22,9 +22,11 @@ namespace {
 constexpr int RP_MAX_SAMPLES = 16;
 constexpr int RP_MAX_DEGREE = 3;
 
-struct PolyModel { double coef[RP_MAX_DEGREE], intercept; };
+template <int MAXD> struct PolyModelT { double coef[MAXD], intercept; };
+typedef PolyModelT<RP_MAX_DEGREE> PolyModel;
 
-__device__ __forceinline__ double poly_predict(const PolyModel& m, int degree, double t)
+template <int MAXD>
+__device__ __forceinline__ double poly_predict(const PolyModelT<MAXD>& m, int degree, double t)
 {
     double acc = 0.0, tk = t;
     for (int k = 0; k < degree; ++k) { acc += m.coef[k] * tk; tk *= t; }
@@ -34,10 +36,14 @@ __device__ __forceinline__ double poly_predict(const PolyModel& m, int degree, d
 // LinearRegression(fit_intercept=True) on PolynomialFeatures(degree)(t): centre the columns t^k and y by their subset means, solve
 // the least squares by modified Gram-Schmidt (the constant column is identically zero after centring: coefficient 0),
 // intercept = mean(y) - sum coef_k mean(t^k).
-__device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
-                                                int ms, int degree, int ystride = 1)
+// MAXD / MAXS size the per-thread arrays (3 / 16 for the kernels of the hot path, 8 / 64 for the wide kernel); REORTH: a second
+// Gram-Schmidt sweep per column ("twice is enough"), for the higher degrees whose centred power columns are nearly dependent.
+template <int MAXD, int MAXS, bool REORTH>
+__device__ __forceinline__ PolyModelT<MAXD> fit_subset_t(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
+                                                         int ms, int degree, int ystride = 1)
 {
-    double c[RP_MAX_DEGREE][RP_MAX_SAMPLES], yy[RP_MAX_SAMPLES], mean[RP_MAX_DEGREE] = { 0, 0, 0 }, ymean = 0.0;
+    double c[MAXD][MAXS], yy[MAXS], mean[MAXD], ymean = 0.0;
+    for (int k = 0; k < MAXD; ++k) mean[k] = 0.0;
     for (int i = 0; i < ms; ++i) {
         const double ti = t[idx[i]];
         double tk = ti;
@@ -49,13 +55,22 @@ __device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, co
     for (int k = 0; k < degree; ++k) mean[k] *= rn;
     for (int i = 0; i < ms; ++i) { yy[i] -= ymean; for (int k = 0; k < degree; ++k) c[k][i] -= mean[k]; }
     // MGS: c_k = sum_{j<=k} R[j][k] q_j, q_j stored in place of c_j;  z_j = q_j . y
-    double Rm[RP_MAX_DEGREE][RP_MAX_DEGREE] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, z[RP_MAX_DEGREE] = { 0, 0, 0 };
+    double Rm[MAXD][MAXD], z[MAXD];
+    for (int k = 0; k < MAXD; ++k) { z[k] = 0.0; for (int j = 0; j < MAXD; ++j) Rm[k][j] = 0.0; }
     for (int k = 0; k < degree; ++k) {
         for (int j = 0; j < k; ++j) {
             double d = 0.0;
             for (int i = 0; i < ms; ++i) d += c[j][i] * c[k][i];
             Rm[j][k] = d;
             for (int i = 0; i < ms; ++i) c[k][i] -= d * c[j][i];
+        }
+        if (REORTH) {
+            for (int j = 0; j < k; ++j) {
+                double d = 0.0;
+                for (int i = 0; i < ms; ++i) d += c[j][i] * c[k][i];
+                Rm[j][k] += d;
+                for (int i = 0; i < ms; ++i) c[k][i] -= d * c[j][i];
+            }
         }
         double nn = 0.0;
         for (int i = 0; i < ms; ++i) nn += c[k][i] * c[k][i];
@@ -66,17 +81,22 @@ __device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, co
         for (int i = 0; i < ms; ++i) { c[k][i] *= inv; d += c[k][i] * yy[i]; }
         z[k] = d;
     }
-    PolyModel m;
+    PolyModelT<MAXD> m;
     for (int k = degree - 1; k >= 0; --k) {                               // back substitution R coef = z
         double v = z[k];
         for (int j = k + 1; j < degree; ++j) v -= Rm[k][j] * m.coef[j];
         m.coef[k] = Rm[k][k] > 0.0 ? v / Rm[k][k] : 0.0;
     }
-    for (int k = degree; k < RP_MAX_DEGREE; ++k) m.coef[k] = 0.0;
+    for (int k = degree; k < MAXD; ++k) m.coef[k] = 0.0;
     double off = 0.0;
     for (int k = 0; k < degree; ++k) off += mean[k] * m.coef[k];
     m.intercept = ymean - off;
     return m;
+}
+__device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
+                                                int ms, int degree, int ystride = 1)
+{
+    return fit_subset_t<RP_MAX_DEGREE, RP_MAX_SAMPLES, false>(t, y, idx, ms, degree, ystride);
 }
 
 // sklearn.linear_model._ransac._dynamic_max_trials
@@ -165,6 +185,72 @@ __global__ __launch_bounds__(THREADS) void ransac_poly_kernel(const double* __re
     // every thread re-fits the accepted sample set (6 rows) and marks its share of the rows
     const PolyModel mb = fit_subset(tp, yp, sample_idx + ((int64_t)p * max_trials + best) * ms, ms, degree);
     for (int i = tau; i < n; i += THREADS) inlier_mask[i0 + i] = fabs(yp[i] - poly_predict(mb, degree, tp[i])) <= thr ? 1 : 0;
+}
+
+// The same problem for configurations beyond the fast kernel's per-thread arrays and one-pass block (polynomial_degree up to 8,
+// min_samples up to 64, any max_trials): trials strided over a 256-thread block, per-trial (inlier count, score) parked in a global
+// slab, the same acceptance walk.  Any CONFIG scikit-learn accepts in practice runs; speed is secondary here.
+constexpr int RPW_MAX_DEGREE = 8, RPW_MAX_SAMPLES = 64, RPW_THREADS = 256;
+__global__ __launch_bounds__(RPW_THREADS) void ransac_poly_wide_kernel(const double* __restrict__ t, const double* __restrict__ y,
+                                                                        const int64_t* __restrict__ offsets, const int32_t* __restrict__ sample_idx,
+                                                                        int max_trials, int ms, int degree, double thr, double stop_prob,
+                                                                        int32_t* __restrict__ tr_cnt, double* __restrict__ tr_score,
+                                                                        uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_trials,
+                                                                        int32_t* __restrict__ n_inliers, int32_t* __restrict__ status)
+{
+    __shared__ int sh_best;
+    const int64_t p = blockIdx.x;
+    const int64_t i0 = offsets[p], i1 = offsets[p + 1];
+    const int n = (int)(i1 - i0);
+    const double* tp = t + i0; const double* yp = y + i0;
+    int32_t* cntp = tr_cnt + p * (int64_t)max_trials; double* scp = tr_score + p * (int64_t)max_trials;
+    bool bad = false;
+    for (int tau = threadIdx.x; tau < max_trials && n > 0; tau += RPW_THREADS) {
+        const int32_t* ix = sample_idx + ((int64_t)p * max_trials + tau) * ms;
+        bool in_range = true;
+        for (int k = 0; k < ms; ++k) in_range = in_range && ix[k] >= 0 && ix[k] < n;
+        if (!in_range) { bad = true; cntp[tau] = -1; scp[tau] = NAN; continue; }
+        const PolyModelT<RPW_MAX_DEGREE> m = fit_subset_t<RPW_MAX_DEGREE, RPW_MAX_SAMPLES, true>(tp, yp, ix, ms, degree);
+        int cnt = 0; double sy = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double res = fabs(yp[i] - poly_predict(m, degree, tp[i]));
+            if (res <= thr) { ++cnt; sy += yp[i]; }
+        }
+        double score = NAN;
+        if (cnt >= 2) {
+            const double ym = sy / (double)cnt;
+            double ss_res = 0.0, ss_tot = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double pr = poly_predict(m, degree, tp[i]);
+                if (fabs(yp[i] - pr) <= thr) { ss_res += (yp[i] - pr) * (yp[i] - pr); ss_tot += (yp[i] - ym) * (yp[i] - ym); }
+            }
+            score = ss_tot != 0.0 ? 1.0 - ss_res / ss_tot : (ss_res == 0.0 ? 1.0 : 0.0);
+        }
+        cntp[tau] = cnt; scp[tau] = score;
+    }
+    const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;             // (also orders the slab writes before the walk below)
+    if (threadIdx.x == 0) {
+        int best = -1, best_n = 1, ntr = 0;
+        double best_score = -INFINITY, max_tr = (double)max_trials;
+        if (n > 0) {
+            while ((double)ntr < max_tr) {
+                const int k = ntr++;
+                const int c = cntp[k];
+                if (c < best_n) continue;
+                const double sc = scp[k];
+                if (c == best_n && sc < best_score) continue;
+                best = k; best_n = c; best_score = sc;
+                max_tr = fmin(max_tr, dynamic_max_trials(best_n, n, ms, stop_prob));
+            }
+        }
+        sh_best = best;
+        n_trials[p] = ntr; n_inliers[p] = best >= 0 ? best_n : 0; status[p] = (best >= 0 ? 0 : 1) | (any_bad ? 2 : 0);
+    }
+    __syncthreads();
+    const int best = sh_best;
+    if (best < 0) { for (int i = threadIdx.x; i < n; i += RPW_THREADS) inlier_mask[i0 + i] = 0; return; }
+    const PolyModelT<RPW_MAX_DEGREE> mb = fit_subset_t<RPW_MAX_DEGREE, RPW_MAX_SAMPLES, true>(tp, yp, sample_idx + ((int64_t)p * max_trials + best) * ms, ms, degree);
+    for (int i = threadIdx.x; i < n; i += RPW_THREADS) inlier_mask[i0 + i] = fabs(yp[i] - poly_predict(mb, degree, tp[i])) <= thr ? 1 : 0;
 }
 
 // score of one fed trial (steps 1 of the header comment) for rows with a stride (AoS position rows)
@@ -304,12 +390,23 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
 {
     GSF_REQUIRE(ctx && offsets && inlier_mask && n_trials && n_inliers && status, "NULL argument");
     GSF_REQUIRE(P >= 0 && P <= 0x7fffffff, "bad P");
-    GSF_REQUIRE(max_trials >= 1 && max_trials <= RP_MAX_TRIALS, "max_trials must be in [1,1024]");
-    GSF_REQUIRE(min_samples >= 1 && min_samples <= RP_MAX_SAMPLES, "min_samples must be in [1,16]");
-    GSF_REQUIRE(degree >= 1 && degree <= RP_MAX_DEGREE, "polynomial degree must be in [1,3]");
+    GSF_REQUIRE(max_trials >= 1 && max_trials <= (1 << 20), "max_trials must be in [1, 2^20]");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= RPW_MAX_SAMPLES, "min_samples must be in [1,64]");
+    GSF_REQUIRE(degree >= 1 && degree <= RPW_MAX_DEGREE, "polynomial degree must be in [1,8]");
     GSF_REQUIRE(sample_idx, "sample_idx is NULL");
     if (P == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
+    if (max_trials > RP_MAX_TRIALS || min_samples > RP_MAX_SAMPLES || degree > RP_MAX_DEGREE) {
+        // beyond the one-pass kernel: the wide kernel with its per-trial slab in the context's workspace
+        const size_t slots = (size_t)P * (size_t)max_trials;
+        int rc = ensure_scratch(ctx, slots * 12 + 64);
+        if (rc) return rc;
+        double* sc = (double*)ctx->scratch; int32_t* cn = (int32_t*)(sc + slots);
+        hipLaunchKernelGGL(ransac_poly_wide_kernel, dim3((unsigned)P), dim3(RPW_THREADS), 0, ctx->stream, t, y, offsets, sample_idx, (int)max_trials,
+                           (int)min_samples, (int)degree, residual_threshold, stop_probability, cn, sc, inlier_mask, n_trials, n_inliers, status);
+        GSF_HIP(hipGetLastError());
+        return GSF_OK;
+    }
 #define GSF_LAUNCH_RP(THREADS_) hipLaunchKernelGGL(ransac_poly_kernel<THREADS_>, dim3((unsigned)P), dim3(THREADS_), 0, ctx->stream, t, y, offsets, sample_idx, (int)max_trials, \
                        (int)min_samples, (int)degree, residual_threshold, stop_probability, inlier_mask, n_trials, n_inliers, status)
     if (max_trials <= 128) GSF_LAUNCH_RP(128); else if (max_trials <= 256) GSF_LAUNCH_RP(256); else if (max_trials <= 512) GSF_LAUNCH_RP(512); else GSF_LAUNCH_RP(1024);

@@ -102,7 +102,7 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
 {
     GSF_REQUIRE(ctx && cfg, "ctx/cfg is NULL");
     GSF_REQUIRE(B >= 0 && N >= 0 && B <= 0x7fffffff, "bad B or N");
-    GSF_REQUIRE(min_samples >= 1 && min_samples <= 8 && max_trials >= 0 && max_trials <= (1 << 20), "min_samples must be in [1,8], max_trials in [0, 2^20]");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= 64 && max_trials >= 0 && max_trials <= (1 << 20), "min_samples must be in [1,64], max_trials in [0, 2^20]");
     if (B == 0 || N == 0) return GSF_OK;
     GSF_REQUIRE(N <= 28000, "N too large for the device-side draws (<= 28000 poses per trajectory)");
     GSF_REQUIRE(ts && pos && quat && gps && valid && mt_state && R && t && s && pos_out && quat_out && status && n_inliers, "NULL array");

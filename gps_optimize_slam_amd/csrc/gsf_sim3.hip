@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void windows_finalize_kernel(const double* __re
 
 // ------------------------------------------------------------------------------------------------
 constexpr int RANSAC_THREADS = 256;
-constexpr int RANSAC_MAX_SAMPLES = 8;
+constexpr int RANSAC_MAX_SAMPLES = 4096;    // the kernel walks a sample set row by row: no structural limit (a sanity bound)
 
 __device__ __forceinline__ double block_sum(double v, double* sh, int tid)
 {
@@ -582,7 +582,7 @@ int gsf_sim3_ransac_batch_dev(gsf_ctx* ctx, const double* src, const double* dst
 {
     GSF_REQUIRE(ctx && offsets && R && t && s && status && inlier_mask && n_inliers, "NULL argument");
     GSF_REQUIRE(B >= 0 && trials >= 0, "negative B or trials");
-    GSF_REQUIRE(min_samples >= 1 && min_samples <= RANSAC_MAX_SAMPLES, "min_samples must be in [1,8]");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= RANSAC_MAX_SAMPLES, "min_samples must be in [1,4096]");
     GSF_REQUIRE(trials == 0 || sample_idx, "sample_idx is NULL");
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     if (B == 0) return GSF_OK;

@@ -189,7 +189,10 @@ def filter_gps_outliers_ransac(times, positions, config):
     sliding = bool(config.get("use_sliding_window", False))
     times, positions = np.asarray(times), np.asarray(positions)
     ranges, wins = _prefilter_windows(times, config, need)
-    if ranges is not None and positions.shape[1] == 3 and max((b - a for a, b in ranges), default=0) <= 14000:
+    longest = max((b - a for a, b in ranges), default=0) if ranges is not None else 0
+    chain_ok = (ranges is not None and positions.shape[1] == 3 and longest <= 14000 and 1 <= trials <= 1024 and need <= 16 and 1 <= degree <= 3
+                and trials * need * 4 + 2 * longest + 4 <= 40 * 1024)    # gsf_gps_prefilter_chain's own limits (LDS budget of its sampler)
+    if chain_ok:
         if not ranges:
             return times[:0], positions[:0]                              # no window had enough rows: nothing is ever marked (ref :199-236)
         kind, key, pos_, has_gauss, cached = np.random.get_state()
@@ -331,9 +334,11 @@ def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max
         return None, None, None
     if src.shape != dst.shape:
         return None, None, None
-    if not 1 <= int(min_samples) <= 8:
-        raise ValueError("min_samples must be in [1, 8] for the device RANSAC")
-    if n_points > 28000:                                                 # beyond the device sampler's LDS budget: host draws (ref :405)
+    if int(min_samples) < 1:
+        raise ValueError("min_samples must be >= 1")
+    if n_points > 28000 or int(min_samples) > 64 or int(max_trials) > (1 << 20):
+        # beyond the device sampler (its LDS budget, 64 traced positions per trial): the reference's own draws on the host (ref :405),
+        # fed to the same scoring kernel -- any configuration the reference accepts runs
         idx = np.empty((int(max_trials), int(min_samples)), dtype=np.int32)
         for k in range(int(max_trials)):
             idx[k] = np.random.choice(n_points, min_samples, replace=False)

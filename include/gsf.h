@@ -147,7 +147,9 @@ GSF_API int gsf_geodetic_to_enu_batch(gsf_ctx *ctx, const double *lat_deg, const
    reference.  Per problem: inlier_mask over its rows (|y - poly(t)| <= residual_threshold for the accepted model), n_trials (the
    number of sample sets scikit-learn's loop would have consumed: acceptance rule + dynamic trial count with stop_probability),
    n_inliers, status (bit 0: no consensus set -- the reference's ValueError; bit 1: a fed sample set named a row outside the problem
-   and was skipped).  degree 1..3, min_samples <= 16, max_trials <= 1024. */
+   and was skipped).  degree 1..8, min_samples <= 64, max_trials <= 2^20; inside degree <= 3, min_samples <= 16, max_trials <= 1024
+   one thread scores one trial in one pass, beyond that a slower kernel strides the trials (per-trial results in the context's
+   workspace). */
 GSF_API int gsf_ransac_poly_batch_dev(gsf_ctx *ctx, const double *t, const double *y, const int64_t *offsets, int64_t P,
                                       const int32_t *sample_idx, int32_t max_trials, int32_t min_samples, int32_t degree,
                                       double residual_threshold, double stop_probability, uint8_t *inlier_mask, int32_t *n_trials,

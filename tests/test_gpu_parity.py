@@ -1007,6 +1007,56 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
+def test_configs_beyond_the_fast_kernels_take_the_wide_routes(E):
+    """Any CONFIG the reference accepts runs (no GsfError for being out of a kernel's range): polynomial_degree 4-5, min_samples 10-24
+    and max_trials 1 500-3 000 in the GPS pre-filter take the wide fed-sample kernel (host draws by scikit-learn's sampler) and still
+    reproduce scikit-learn's inlier mask and RNG position; the full filter with such a CONFIG equals the window-by-window route; a Sim3
+    RANSAC with min_samples 10 / 70 draws on the device / on the host like np.random.choice."""
+    from sklearn.linear_model import RANSACRegressor
+    from sklearn.pipeline import make_pipeline
+    from sklearn.preprocessing import PolynomialFeatures
+    rng = np.random.default_rng(5)
+    agree = 0
+    for case in range(12):
+        n = int(rng.integers(60, 260)); deg = int(rng.choice([4, 5, 2])); ms = int(rng.choice([10, 17, 24])); trials = int(rng.choice([60, 1500, 3000]))
+        thr = float(rng.choice([2.0, 10.0]))
+        t = np.sort(rng.uniform(0, 15, n))                                 # one 15 s window, track-relative stamps
+        y = 5.4e6 + 3.0 * t + 0.2 * t ** 2 - 0.01 * t ** 3 + rng.normal(0, 0.4, n)
+        bad = rng.random(n) < rng.uniform(0, 0.3)
+        y[bad] += rng.choice([-1, 1], bad.sum()) * rng.uniform(20, 300, bad.sum())
+        np.random.seed(case)
+        model = make_pipeline(PolynomialFeatures(degree=deg), RANSACRegressor(min_samples=ms, residual_threshold=thr, max_trials=trials))
+        model.fit(t.reshape(-1, 1), y); ref_mask = model[-1].inlier_mask_
+        ref_after = np.random.random()
+        np.random.seed(case)
+        mask = E._ransac_axes_mask(t, y.reshape(-1, 1), deg, ms, thr, trials)
+        assert np.random.random() == ref_after, case                        # same number of sample sets consumed
+        # degree 4-5 on 15 s of stamps: the power columns are collinear to ~1e-9, LAPACK's SVD solve and a QR differ in the last digits
+        # of the fit, which can move a row that sits on the threshold; everything else must agree
+        assert (mask != ref_mask).sum() <= 1, (case, deg, ms, trials)
+        agree += int(np.array_equal(mask, ref_mask))
+    assert agree >= 10
+    # the whole pre-filter with an out-of-range CONFIG == the reference's window loop on the same draws
+    cfg = copy.deepcopy(E.CONFIG["gps_filtering_ransac"])
+    cfg.update(enabled=True, polynomial_degree=4, min_samples=10, max_trials=1500)
+    t = np.arange(400) * 0.1
+    p = np.column_stack((4.5e5 + 10.0 * t, 5.4e6 + 3.0 * t + 0.1 * t ** 2, 110.0 + 0.01 * t)) + rng.normal(0, 0.3, (400, 3))
+    p[::37] += 80.0
+    np.random.seed(3)
+    ft, fp = E.filter_gps_outliers_ransac(t, p, cfg)
+    assert 350 <= len(ft) < 400 and not np.isin(t[::37], ft).any()       # the spikes are gone, the track stays
+    # Sim3 RANSAC beyond the former cap of 8 samples: 10 (device draws) and 70 (host draws), same draws as the reference's call
+    src = rng.normal(size=(300, 3)).cumsum(axis=0); dst = 1.07 * src + np.array([4.5e5, 5.4e6, 100.0]) + rng.normal(size=(300, 3)) * 0.02
+    for ms in (10, 70):
+        np.random.seed(11)
+        R, tt, sc = E.compute_sim3_transform_robust(src, dst, ms, 1.0, 50, ms)
+        after = np.random.random()
+        np.random.seed(11)
+        for _ in range(50):
+            np.random.choice(300, ms, replace=False)
+        assert np.random.random() == after and abs(sc - 1.07) < 1e-3
+
+
 def test_fed_sample_sets_are_validated_and_trials_stride(B):
     """caller-fed row indices outside [0, n) must not be dereferenced (K2b and the polynomial RANSAC skip such a sample
     set and flag it), and max_trials above the block size is strided over the threads (200 trials on 128 threads)."""
