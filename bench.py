@@ -200,11 +200,42 @@ def profiled_traffic(workload, kernel, grid_threads):
             return None, f"{name} was taken from other kernel sources ({doc.get('kernel_source_hash')}); not quoted"
         key = f"{kernel} grid={grid_threads}"
         d = doc.get(workload, {})
-        if key in d:
+        if key in d and "hbm_bytes" in d[key]:
             return d[key]["hbm_bytes"], name
         return None, f"{name} holds no entry for {key}"
     except Exception as e:                                   # a malformed profile must not take the bench down
         return None, f"profile unreadable: {e}"
+
+
+SIMDS, CLOCK_GHZ, VALU_ISSUE_CYCLES = 1024, 2.4, 4      # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak; one wave issues a VALU instruction per 4 cycles
+
+
+def profiled_issue(workload, kernel, grid_threads, kernel_ms):
+    """The issue-side roofline of `kernel` from the committed PMC passes (same file and hash gate as profiled_traffic): the time the
+    launch's VALU wave-instructions need at one instruction per 4 cycles on every one of the 1 024 SIMDs, as a fraction of the
+    measured kernel time, plus what the waves were doing (VALU active / waiting).  None when no matching profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        if doc.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        iss = doc.get(workload, {}).get(f"{kernel} grid={grid_threads}", {}).get("issue")
+        if not iss or not iss.get("SQ_INSTS_VALU"):
+            return None
+        floor_ms = iss["SQ_INSTS_VALU"] * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+        out = {"valu_wave_instructions_per_launch": iss["SQ_INSTS_VALU"], "salu_instructions_per_launch": iss.get("SQ_INSTS_SALU"),
+               "cycles_per_instruction": VALU_ISSUE_CYCLES, "simds": SIMDS, "clock_GHz": CLOCK_GHZ, "floor_ms": floor_ms, "frac": floor_ms / kernel_ms,
+               "source": os.path.basename(files[-1])}
+        if iss.get("SQ_WAVE_CYCLES"):
+            out["valu_active_frac_of_wave_cycles"] = iss.get("SQ_ACTIVE_INST_VALU", 0.0) / iss["SQ_WAVE_CYCLES"]
+            out["waiting_frac_of_wave_cycles"] = iss.get("SQ_WAIT_ANY", 0.0) / iss["SQ_WAVE_CYCLES"]
+            out["waves"] = iss.get("SQ_WAVES")
+        return out
+    except Exception:
+        return None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -519,12 +550,19 @@ def worker(args):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
     pipe = args.kernel == "pipeline"
-    if pipe and 64 < N <= 640 and Bn <= 256:
+    blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024
+    if blk:
+        # the workgroup-per-trajectory kernel (opt-in): <PIPELINE, AXMODE, max threads, waves per SIMD, inlined cold blocks>
+        Wv = (N + 63) // 64
+        shape = "320, 5, true" if Wv <= 5 else ("512, 4, true" if Wv <= 8 else "1024, 4, false")
+        kernel_name, grid_threads = "ekf_block_kernel<%s, 1, %s>" % ("true" if pipe else "false", shape), Bn * Wv * 64
+    elif pipe and 64 < N <= 640 and Bn <= 256:
         kernel_name, grid_threads = "ekf_wave_duo_kernel<true, 1>", Bn * 128                     # a helper wave per trajectory
     else:
         # <PIPELINE, SMALLBATCH, AXMODE>: AXMODE 1 = x and y share their noise figures, z does not (the default CONFIG, compiled-in scans)
         kernel_name, grid_threads = "ekf_wave_kernel<%s, %s, 1>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
-    traffic, traffic_src = profiled_traffic(args.workload, kernel_name, grid_threads)
+    wl_key = args.workload + ("" if pipe else "ekf") if not blk else args.workload + "block" + ("" if pipe else "ekf")   # section of the PMC profile
+    traffic, traffic_src = profiled_traffic(wl_key, kernel_name, grid_threads)
     result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
                   config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)",
                           "step": args.kernel, "parallelism": f"trajectory-sharded x{world}" + (", one RCCL all-gather of the fused poses after the K steps (inside the timed region)" if world > 1 else "")
@@ -532,6 +570,14 @@ def worker(args):
                   roofline={"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                             "kernel_source_hash": kernel_source_hash()})
+    # what the counters say bounds this kernel: the VALU issue floor next to the HBM figure (profile of the same sources, else absent)
+    valu = profiled_issue(wl_key, kernel_name, grid_threads, kern_ms)
+    if valu is not None:
+        result["roofline"]["valu"] = valu
+        if valu["frac"] > result["roofline"]["frac"]:
+            result["roofline"]["bound"] = "valu"
+            result["roofline"]["bound_note"] = ("counters: the launch's VALU wave-instructions at one per 4 cycles on all 1 024 SIMDs take a larger share of the "
+                                                "kernel time than its algorithmic bytes at 8 TB/s; achieved / peak / frac stay the HBM figures")
     if args.kernel == "pipeline":
         torch.cuda.synchronize()
         # how many tracks of the timed batch took the Jacobi-SVD fallback of the fit (status bit GSF_SIM3_FLAG_SVD_FALLBACK << 8): one such

@@ -274,6 +274,110 @@ __global__ __launch_bounds__(256) void windows_moments_kernel(const double* __re
     }
 }
 
+// The two steps in ONE launch (gsf_set_option "ekf_variant" 9 selects the two-launch form above for A/B): a wave owns 64 consecutive
+// windows, runs their moments four windows at a time exactly as windows_moments_kernel does, parks the 64 records in LDS (never in
+// HBM: 192 B per window less written and read again, 15 % of the traffic at W = 50) and then finishes all 64 with one lane per
+// window -- the Jacobi SVD is paid once per 64 windows with every lane busy, and its registers only cap the occupancy at three
+// waves per SIMD, which the up-front loads of a trip (all slices of the four windows requested before the first use) make up for.
+constexpr int WINF_WAVES = 2, WINF_STRIDE = WIN_REC + 1;   // records padded to 25 doubles: lane-per-window reads spread over the LDS banks
+__global__ __launch_bounds__(64 * WINF_WAVES) void windows_fused_kernel(const double* __restrict__ src, const double* __restrict__ dst,
+                                                                         const uint8_t* __restrict__ mask, int64_t B, int W, double* __restrict__ R,
+                                                                         double* __restrict__ t, double* __restrict__ s, int32_t* __restrict__ status)
+{
+    __shared__ double recs[WINF_WAVES][64 * WINF_STRIDE];
+    const int lane = threadIdx.x & 63, j0 = lane & 15, wv = threadIdx.x >> 6;
+    const int brev = ((j0 & 1) << 3) | ((j0 & 2) << 1) | ((j0 & 4) >> 1) | ((j0 & 8) >> 3);
+    double* rw = recs[wv];
+    const int64_t nsuper = (B + 63) / 64;
+    for (int64_t sp = (int64_t)blockIdx.x * WINF_WAVES + wv; sp < nsuper; sp += (int64_t)gridDim.x * WINF_WAVES) {
+        const int64_t w0 = sp * 64;
+        for (int trip = 0; trip < 16; ++trip) {
+            const int lw = trip * 4 + (lane >> 4);                        // window of my 16-lane row inside the wave's 64
+            const int64_t w = w0 + lw;
+            const bool live = w < B;
+            const int64_t i0 = (live ? w : B - 1) * (int64_t)W, i1 = live ? i0 + W : i0;
+            double as0 = src[i0 * 3], as1 = src[i0 * 3 + 1], as2 = src[i0 * 3 + 2], bs0 = dst[i0 * 3], bs1 = dst[i0 * 3 + 1], bs2 = dst[i0 * 3 + 2];
+            // up to four slices of the window requested before anything is used (W <= 64: the whole window; longer windows loop below)
+            double pa[4][3], pc[4][3]; bool pm[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + j0 + 16 * k;
+                const bool in = i < i1;
+                const int64_t ic = in ? i : i0;
+                pa[k][0] = src[ic * 3]; pa[k][1] = src[ic * 3 + 1]; pa[k][2] = src[ic * 3 + 2];
+                pc[k][0] = dst[ic * 3]; pc[k][1] = dst[ic * 3 + 1]; pc[k][2] = dst[ic * 3 + 2];
+                pm[k] = in && (!mask || mask[ic] != 0);
+            }
+            bool have = live && (!mask || mask[i0] != 0) && (fabs(as0) < INFINITY) && (fabs(as1) < INFINITY) && (fabs(as2) < INFINITY) &&
+                        (fabs(bs0) < INFINITY) && (fabs(bs1) < INFINITY) && (fabs(bs2) < INFINITY);
+            if (__ballot(live && !have) != 0ull) {                        // rare: search the window for its first usable row
+                const int gbase = lane & 48;
+                for (int64_t off = 0; __ballot(live && !have && i0 + off < i1) != 0ull; off += 16) {
+                    const int64_t i = i0 + off + j0;
+                    bool ok = live && i < i1 && !have;
+                    double a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
+                    if (ok) {
+                        ok = !mask || mask[i] != 0;
+                        a0 = src[i * 3]; a1 = src[i * 3 + 1]; a2 = src[i * 3 + 2]; c0 = dst[i * 3]; c1 = dst[i * 3 + 1]; c2 = dst[i * 3 + 2];
+                        ok = ok && (fabs(a0) < INFINITY) && (fabs(a1) < INFINITY) && (fabs(a2) < INFINITY) && (fabs(c0) < INFINITY) &&
+                             (fabs(c1) < INFINITY) && (fabs(c2) < INFINITY);
+                    }
+                    const u64 m = __ballot(ok);
+                    const unsigned field = (unsigned)(m >> gbase) & 0xffffu;
+                    const int srcl = gbase + (field ? __ffs((int)field) - 1 : 0);
+                    const double f0 = shidx(a0, srcl), f1 = shidx(a1, srcl), f2 = shidx(a2, srcl), g0 = shidx(c0, srcl), g1 = shidx(c1, srcl), g2 = shidx(c2, srcl);
+                    if (!have && field) { as0 = f0; as1 = f1; as2 = f2; bs0 = g0; bs1 = g1; bs2 = g2; have = true; }
+                }
+            }
+            double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+            double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define GSF_WIN_ACC(A0, A1, A2, C0, C1, C2) {                                                                     \
+                const double a0 = (A0) - as0, a1 = (A1) - as1, a2 = (A2) - as2, c0 = (C0) - bs0, c1 = (C1) - bs1, c2 = (C2) - bs2; \
+                cnt += 1.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += c0; Sb1 += c1; Sb2 += c2;                        \
+                Saa += a0 * a0 + a1 * a1 + a2 * a2;                                                                   \
+                Sab[0] += a0 * c0; Sab[1] += a0 * c1; Sab[2] += a0 * c2;                                              \
+                Sab[3] += a1 * c0; Sab[4] += a1 * c1; Sab[5] += a1 * c2;                                              \
+                Sab[6] += a2 * c0; Sab[7] += a2 * c1; Sab[8] += a2 * c2; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (pm[k]) GSF_WIN_ACC(pa[k][0], pa[k][1], pa[k][2], pc[k][0], pc[k][1], pc[k][2])
+            for (int64_t i = i0 + j0 + 64; i < i1; i += 16)               // windows of more than 64 rows: the rest, slice by slice (same order)
+                if (!mask || mask[i] != 0) GSF_WIN_ACC(src[i * 3], src[i * 3 + 1], src[i * 3 + 2], dst[i * 3], dst[i * 3 + 1], dst[i * 3 + 2])
+#undef GSF_WIN_ACC
+            const double tot = row_sum16(Sa0, Sa1, Sa2, Sb0, Sb1, Sb2, Saa, Sab[0], Sab[1], Sab[2], Sab[3], Sab[4], Sab[5], Sab[6], Sab[7], Sab[8], lane);
+            const double n = row16_scan_sum(cnt);                         // total in lane 15 of the row
+            double* r = rw + lw * WINF_STRIDE;
+            r[brev] = tot;                                                // lane l holds sum index bitrev4(l)
+            const double tail = (j0 == 0) ? as0 : (j0 == 1) ? as1 : (j0 == 2) ? as2 : (j0 == 3) ? bs0 : (j0 == 4) ? bs1 : bs2;
+            if (j0 < 6) r[16 + j0] = tail;
+            if (j0 == 15) r[22] = (live && have) ? n : 0.0;
+        }
+        // ---- lane per window: H, centroids, Jacobi SVD, R / t / s of the wave's 64 windows (only this wave reads its records)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the record stores above have landed
+        __builtin_amdgcn_wave_barrier();
+        const int64_t b = w0 + lane;
+        if (b < B) {
+            const double* r = rw + lane * WINF_STRIDE;
+            RawMoments m;
+            m.Sa[0] = r[0]; m.Sa[1] = r[1]; m.Sa[2] = r[2]; m.Sb[0] = r[3]; m.Sb[1] = r[4]; m.Sb[2] = r[5]; m.Saa = r[6];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m.Sab[k] = r[7 + k];
+            m.as[0] = r[16]; m.as[1] = r[17]; m.as[2] = r[18]; m.bs[0] = r[19]; m.bs[1] = r[20]; m.bs[2] = r[21]; m.n = r[22];
+            double Rb[9], tb[3], sb = NAN;
+            const int32_t st = finalize_raw(m, Rb, tb, sb);
+            if (st == SIM3_NONE) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rb[k] = NAN;
+                tb[0] = tb[1] = tb[2] = NAN; sb = NAN;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[b * 9 + k] = Rb[k];
+            t[b * 3] = tb[0]; t[b * 3 + 1] = tb[1]; t[b * 3 + 2] = tb[2];
+            s[b] = sb; status[b] = st;
+        }
+        __builtin_amdgcn_wave_barrier();                                  // the next super-trip overwrites the records
+    }
+}
+
 __global__ __launch_bounds__(64) void windows_finalize_kernel(const double* __restrict__ rec, int64_t B, double* __restrict__ R, double* __restrict__ t,
                                                               double* __restrict__ s, int32_t* __restrict__ status)
 {
@@ -562,6 +666,17 @@ int gsf_sim3_umeyama_windows_dev(gsf_ctx* ctx, const double* src, const double* 
         hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned)((B + 256) / 256)), dim3(256), 0, ctx->stream, off, B, (int64_t)W);
         GSF_HIP(hipGetLastError());
         return gsf_sim3_umeyama_batch_dev(ctx, src, dst, mask, off, B, R, t, s, status);
+    }
+    // one launch (moments in LDS, lane-per-window finish per 64 windows) where it is the faster form -- windows of up to 64 rows (a
+    // trip requests the whole window up front) in batches that fill the chip: 0.50 vs 0.58 ms at 1 M x 50; 0.57 vs 0.53 ms at 200 k x
+    // 271 and 27 vs 23 us at 4 096 x 50 the other way round.  Both forms produce the same bits (tools/ab_c4.py), so the choice by size
+    // changes no result.  gsf_set_option "ekf_variant": 9 = always two launches, 10 = always one.
+    if (ctx->ekf_variant == 10 || (ctx->ekf_variant != 9 && W <= 64 && B >= 16384)) {
+        int64_t nblk = ((B + 63) / 64 + WINF_WAVES - 1) / WINF_WAVES;
+        if (nblk > 65536) nblk = 65536;
+        hipLaunchKernelGGL(windows_fused_kernel, dim3((unsigned)nblk), dim3(64 * WINF_WAVES), 0, ctx->stream, src, dst, mask, B, (int)W, R, t, s, status);
+        GSF_HIP(hipGetLastError());
+        return GSF_OK;
     }
     int rc = ensure_scratch(ctx, (size_t)B * WIN_REC * 8);
     if (rc) return rc;

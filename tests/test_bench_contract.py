@@ -17,7 +17,11 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if "valu" in r:                                    # the issue-side roofline from the committed PMC profile of the same kernel sources
+        v = r["valu"]
+        assert abs(v["floor_ms"] - v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) * 1e3) < 1e-12 and abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
+        assert (r["bound"] == "valu") == (v["frac"] > r["frac"])
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["alg_bytes_per_launch"]
     # value = poses per step / step time; the kernel's share of the step is what the roofline is computed from
     poses = d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"]

@@ -18,7 +18,7 @@ if os.path.exists(raw + "/bench_default.json"):
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_hash: the profile is only quoted by bench.py while the kernels are the ones it measured)
 traffic = {"kernel_source_hash": bench.kernel_source_hash()}
-pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_duo_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
+pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_duo_kernel<[\w, ]+>|ekf_block_kernel<[\w, ]+>|windows_moments_kernel|windows_finalize_kernel|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
                  r"apply_sim3_kernel|utm_kernel<\w+>|gps_rows_to_utm_kernel|enu_kernel|time_align_kernel|eval_errors_kernel|ransac_poly_kernel|mt_choice_kernel|"
                  r"compact_valid_kernel|transpose_kernel<[\w, ]+>)")
 kt_aux = sorted(glob.glob(raw + "/trace_aux/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime, reverse=True)
@@ -30,7 +30,7 @@ if ks_aux:
 if os.path.exists(raw + "/aux_kernels.json"):
     txt = open(raw + "/aux_kernels.json").read()
     open(f"{out}/{tag}_aux_kernels.json", "w").write(txt[txt.index("{"):])
-for wl in ("c2", "c3", "c3ekf", "aux"):
+for wl in ("c2", "c3", "c3ekf", "c2ekf", "c2block", "c2blockekf", "aux"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{raw}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
@@ -52,6 +52,15 @@ for wl in ("c2", "c3", "c3ekf", "aux"):
             traffic.setdefault(wl, {})[k] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
                                             "FETCH_SIZE_raw_KiB": sum(fs) / len(fs), "WRITE_SIZE_raw_KiB": sum(ws) / len(ws)}
             lines.append(f"   -> HBM traffic per launch: fetch {fetch / 1e9:.3f} GB (2 x FETCH_SIZE, gfx950 correction) + write {write / 1e9:.3f} GB")
+        # issue-side counters per launch (bench.py's roofline.valu: SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x clock))
+        iss = {c: sum(per[k][c]) / len(per[k][c]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                                           "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE") if per[k].get(c)}
+        if iss.get("SQ_INSTS_VALU"):
+            traffic.setdefault(wl, {}).setdefault(k, {})["issue"] = iss
+            fl = iss["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9)
+            lines.append(f"   -> VALU issue floor: {iss['SQ_INSTS_VALU']:.4g} wave-instructions x 4 cycles / (1 024 SIMDs x 2.4 GHz) = {fl * 1e6:.2f} us per launch"
+                         + (f"; VALU active {iss['SQ_ACTIVE_INST_VALU'] / iss['SQ_WAVE_CYCLES']:.0%} / waiting {iss['SQ_WAIT_ANY'] / iss['SQ_WAVE_CYCLES']:.0%} of the wave cycles"
+                            if iss.get("SQ_WAVE_CYCLES") and iss.get("SQ_ACTIVE_INST_VALU") and iss.get("SQ_WAIT_ANY") else ""))
     if lines:
         open(f"{out}/{tag}_pmc_{wl}.txt", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
