@@ -835,7 +835,7 @@ def c4_windows(torch, B, timed, nw=1_000_000, W=50):
     # as well determined as the window's lateral extent allows, so the residual is the meaningful figure, not R - R_planted)
     resid = (s[:, None, None] * torch.einsum("bij,bwj->bwi", R.view(nw, 3, 3), src) + t[:, None, :] - dst).norm(dim=2)
     res = {"ms": ms, "windows_per_s": nw / ms * 1e3, "alg_bytes_per_window": 48 * W + 104, "alg_GBps": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
-           "kernels": "windows_moments_kernel + windows_finalize_kernel", "status_nonzero": int((st != 0).sum().item()),
+           "kernels": "windows_fused_kernel (moments in LDS + lane-per-window closed form, one launch)", "status_nonzero": int((st != 0).sum().item()),
            "planted_transform_recovered": {"max_abs_scale_err": float((s - sp).abs().max().item()), "mean_abs_scale_err": float((s - sp).abs().mean().item()),
                                            "fit_residual_rms_m": float(resid.pow(2).mean().sqrt().item()), "fit_residual_max_m": float(resid.max().item()),
                                            "planted_noise_sigma_m_per_axis": 0.02}}
