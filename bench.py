@@ -359,6 +359,7 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
                 time.sleep(inject_stall_s)
             if mode is not None and collector is None:
                 collector = D.PoseCollector(dev, s_comm)
+                info["rccl_version"] = collector.rccl_version
             def gather(k):                                                 # on s_comm
                 send = out[k * P * 7:(k + 1) * P * 7]
                 if mode is None:

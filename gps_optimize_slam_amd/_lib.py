@@ -113,6 +113,7 @@ SIGNATURES = {
     "gsf_ekf_process_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), C.POINTER(_f64), _i32, _vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp]),
     "gsf_rts_smoother_segment_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gsf_comm_unique_id": (C.c_int, [_vp]),
+    "gsf_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int32)]),
     "gsf_comm_init_rank": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "gsf_comm_destroy": (C.c_int, [_vp]),
     "gsf_allgather_poses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64]),

@@ -28,12 +28,14 @@ struct UniqueId { char internal[128]; };                                        
 typedef int (*uid_fn)(UniqueId*);
 typedef int (*init_fn)(void**, int, UniqueId, int);                                         // ncclCommInitRank (id by value)
 typedef int (*destroy_fn)(void*);
+typedef int (*version_fn)(int*);                                                            // ncclGetVersion
 
 struct Rccl {
     void* h = nullptr;
     allgather_fn allgather = nullptr; sendrecv_fn send = nullptr; sendrecv_fn recv = nullptr;
     group_fn gstart = nullptr, gend = nullptr; rank_fn crank = nullptr, csize = nullptr; errstr_fn errstr = nullptr;
-    uid_fn uid = nullptr; init_fn init = nullptr; destroy_fn destroy = nullptr;
+    uid_fn uid = nullptr; init_fn init = nullptr; destroy_fn destroy = nullptr; version_fn version = nullptr;
+    int ver = 0;                                                                             // e.g. 22105 for 2.21.5; 0 = unknown
     char why[256] = "";
     bool ok() const { return h && allgather && send && recv && gstart && gend && crank && csize && uid && init && destroy; }
 };
@@ -55,6 +57,8 @@ Rccl* rccl()
         r.errstr = (errstr_fn)dlsym(r.h, "ncclGetErrorString");
         r.uid = (uid_fn)dlsym(r.h, "ncclGetUniqueId"); r.init = (init_fn)dlsym(r.h, "ncclCommInitRank");
         r.destroy = (destroy_fn)dlsym(r.h, "ncclCommDestroy");
+        r.version = (version_fn)dlsym(r.h, "ncclGetVersion");
+        if (r.version && r.version(&r.ver) != 0) r.ver = 0;
         if (!r.ok()) snprintf(r.why, sizeof r.why, "a required nccl* symbol is missing from librccl.so");
     });
     return &r;
@@ -74,10 +78,21 @@ int need_rccl(Rccl*& R, const char* who)
 #define GSF_NCCL(call)                                                                                     \
     do {                                                                                                   \
         int e__ = (call);                                                                                  \
-        if (e__ != 0) { set_error("RCCL error %d (%s) in %s", e__, R->errstr ? R->errstr(e__) : "?", #call); return GSF_ERR_HIP; } \
+        if (e__ != 0) { set_error("RCCL (version %d) error %d (%s) in %s", R->ver, e__, R->errstr ? R->errstr(e__) : "?", #call); return GSF_ERR_HIP; } \
     } while (0)
 
 extern "C" {
+
+// The resolved library's ncclGetVersion (MAJOR * 10000 + MINOR * 100 + PATCH): logged by the callers, so that a mismatch between the
+// signatures assumed above (NCCL 2.x: 128-byte id by value) and the librccl.so of the process shows up as a number, not as a stall.
+int gsf_comm_rccl_version(int32_t* version)
+{
+    GSF_REQUIRE(version, "version is NULL");
+    Rccl* R; int rc = need_rccl(R, "gsf_comm_rccl_version");
+    if (rc) return rc;
+    *version = R->ver;
+    return GSF_OK;
+}
 
 int gsf_comm_unique_id(uint8_t* id128)
 {
@@ -97,6 +112,7 @@ int gsf_comm_init_rank(gsf_ctx* ctx, const uint8_t* id128, int32_t world, int32_
     *comm = nullptr;
     Rccl* R; int rc = need_rccl(R, "gsf_comm_init_rank");
     if (rc) return rc;
+    GSF_REQUIRE(R->ver == 0 || (R->ver >= 20000 && R->ver < 30000), "the resolved librccl.so is not an NCCL 2.x API (ncclGetVersion): refusing to call it with 2.x signatures");
     GSF_HIP(hipSetDevice(ctx->device));
     UniqueId u;
     memcpy(u.internal, id128, sizeof u.internal);

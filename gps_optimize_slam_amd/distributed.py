@@ -112,6 +112,9 @@ class PoseCollector:
             raise RuntimeError("PoseCollector needs an initialised torch.distributed process group (to ship the RCCL id)")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self._L = _lib.load()
+        v = C.c_int32(0)
+        _lib.check(self._L.gsf_comm_rccl_version(C.byref(v)))
+        self.rccl_version = int(v.value)                         # e.g. 22105: recorded by the bench next to the leg it ran
         stream = stream or torch.cuda.current_stream(device)
         self.stream = stream
         self.ctx = _lib.Context(torch.device(device).index or 0, stream.cuda_stream)

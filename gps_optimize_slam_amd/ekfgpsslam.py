@@ -47,6 +47,14 @@ CONFIG = {
 }
 
 
+VERBOSE = False     # True: the Sim3 functions print the reference's diagnostics (ref :396-425, :433, :446, :450) -- same numbers, in English
+
+
+def _say(msg):
+    if VERBOSE:
+        print(msg)
+
+
 def _ctx():
     return _lib.default_context()
 
@@ -313,13 +321,19 @@ def compute_sim3_transform(src, dst):
     if n_points < 3:
         return None, None, None
     if src.shape != dst.shape or src.ndim != 2 or src.shape[1] != 3:
+        _say("Error: Sim3: source/target points must both be Nx3.")                             # ref :433
         return None, None, None
     src, dst = np.ascontiguousarray(src), np.ascontiguousarray(dst)
     off = np.array([0, n_points], dtype=np.int64)
     R, t, s, st = np.empty((1, 9)), np.empty((1, 3)), np.empty(1), np.zeros(1, dtype=np.int32)
     check(_lib.load().gsf_sim3_umeyama_batch(_ctx().handle, hptr(src), hptr(dst), None, hptr(off), 1, hptr(R), hptr(t), hptr(s), hptr(st)))
     if st[0] == _lib.SIM3_NONE:
+        _say("Error: Sim3: linear-algebra failure (non-finite cross-covariance).")              # ref :453
         return None, None, None
+    if st[0] & 2:
+        _say("Warning: source point set has (near) zero variance; scale defaults to 1.0.")      # ref :446
+    if st[0] & 4:
+        _say("Warning: computed scale is tiny (<= 1e-6); reset to 1.0.")                        # ref :450
     return R.reshape(3, 3), t.reshape(3), float(s[0])
 
 
@@ -331,9 +345,12 @@ def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max
     src, dst = np.asarray(src, dtype=np.float64), np.asarray(dst, dtype=np.float64)
     n_points = src.shape[0]
     if n_points < min_samples:
+        _say(f"Error: Sim3 RANSAC: too few input points ({n_points} from {point_description}), at least {min_samples} needed.")   # ref :396
         return None, None, None
     if src.shape != dst.shape:
+        _say(f"Error: Sim3 RANSAC: source and target ({point_description}) differ in shape ({src.shape} vs {dst.shape}).")          # ref :399
         return None, None, None
+    _say(f"  Sim3 RANSAC on {n_points} {point_description} (threshold={residual_threshold}m, trials={max_trials}, min samples={min_samples})...")   # ref :403
     if int(min_samples) < 1:
         raise ValueError("min_samples must be >= 1")
     if n_points > 28000 or int(min_samples) > 64 or int(max_trials) > (1 << 20):
@@ -342,7 +359,9 @@ def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max
         idx = np.empty((int(max_trials), int(min_samples)), dtype=np.int32)
         for k in range(int(max_trials)):
             idx[k] = np.random.choice(n_points, min_samples, replace=False)
-        return sim3_ransac_with_indices(src, dst, idx, residual_threshold, min_inliers_needed)[:3]
+        R_, t_, s_, _, nin_ = sim3_ransac_with_indices(src, dst, idx, residual_threshold, min_inliers_needed)
+        _robust_report(R_, s_, int(nin_), n_points, min_inliers_needed, point_description)
+        return R_, t_, s_
     src, dst = np.ascontiguousarray(src), np.ascontiguousarray(dst)
     kind, key, pos, has_gauss, cached = np.random.get_state()
     state = np.concatenate([key.astype(np.uint32), np.array([pos], dtype=np.uint32)])
@@ -353,9 +372,24 @@ def compute_sim3_transform_robust(src, dst, min_samples, residual_threshold, max
                                                float(residual_threshold), int(min_inliers_needed), hptr(R), hptr(t), hptr(s), hptr(st), hptr(mask),
                                                hptr(nin)))
     np.random.set_state((kind, state[:624], int(state[624]), has_gauss, cached))
-    if st[0] & _lib.SIM3_NONE:
+    none = bool(st[0] & _lib.SIM3_NONE)
+    _robust_report(None if none else R, None if none else float(s[0]), int(nin[0]), n_points, min_inliers_needed, point_description)
+    if none:
         return None, None, None
     return R.reshape(3, 3), t.reshape(3), float(s[0])
+
+
+def _robust_report(R, scale, max_inliers, n_points, min_inliers_needed, point_description):
+    """the reference's progress lines of compute_sim3_transform_robust (ref :415-425), printed when VERBOSE"""
+    if not VERBOSE:
+        return
+    print(f"  Sim3 RANSAC done: best inlier count {max_inliers}/{n_points}.")                                                     # ref :415
+    if max_inliers < min_inliers_needed:
+        print(f"Error: Sim3 RANSAC: best inlier count too small ({max_inliers} from {point_description}), {min_inliers_needed} needed.")   # ref :417
+    elif R is None:
+        print(f"Error: Sim3 RANSAC: the final fit on {max_inliers} inliers failed.")                                             # ref :423
+    else:
+        print(f"  Final Sim3 from {max_inliers} inliers: scale={scale:.4f}")                                                     # ref :419, :425
 
 
 def sim3_ransac_with_indices(src, dst, sample_idx, residual_threshold, min_inliers_needed):

@@ -349,6 +349,8 @@ GSF_API int gsf_rts_smoother_segment_batch(gsf_ctx *ctx, const double *states_fi
    receives every rank's fused poses.  RCCL is resolved at run time (dlopen).
    gsf_comm_unique_id: 128-byte ncclUniqueId (rank 0 creates it, the host ships it to the other ranks by any side channel);
    gsf_comm_init_rank: collective over all `world` processes, device = the context's; gsf_comm_destroy frees the communicator. */
+/* ncclGetVersion of the librccl.so the library resolved (MAJOR*10000 + MINOR*100 + PATCH; 0 = the symbol is missing) */
+GSF_API int gsf_comm_rccl_version(int32_t *version);
 GSF_API int gsf_comm_unique_id(uint8_t *id128);
 GSF_API int gsf_comm_init_rank(gsf_ctx *ctx, const uint8_t *id128, int32_t world, int32_t rank, void **comm);
 GSF_API int gsf_comm_destroy(void *comm);

@@ -472,6 +472,9 @@ def test_rccl_own_communicator_single_rank(B):
             torch.cuda.synchronize()
             assert torch.equal(send, recv), (mode, chunk)
         assert L.gsf_comm_init_rank(ctx.handle, ident, 1, 3, C.byref(C.c_void_p())) != 0      # rank out of range: refused before RCCL is called
+        v = C.c_int32(0)
+        _lib.check(L.gsf_comm_rccl_version(C.byref(v)))
+        assert 20000 <= v.value < 30000, v.value                           # the resolved librccl.so speaks the NCCL 2.x API the wrapper assumes
     finally:
         _lib.check(L.gsf_comm_destroy(comm))
 
@@ -778,6 +781,29 @@ def test_c5_shard_full_size_checksum_invariance(B):
         del part, o1
     del bt, out
     torch.cuda.empty_cache()
+
+
+def test_verbose_sim3_diagnostics(E, golden, capsys):
+    """ekfgpsslam.VERBOSE prints the reference's progress lines of the Sim3 functions (ref :396-425, :446, :450) with the same numbers;
+    off (the default) the functions are silent."""
+    g = golden("kat_bundled.npz")
+    src, dst = g["pos"], g["gt"]
+    np.random.seed(1)
+    E.compute_sim3_transform_robust(src, dst, 4, 4.0, 50, 4, "pts")
+    assert capsys.readouterr().out == ""
+    E.VERBOSE = True
+    try:
+        np.random.seed(1)
+        R, t, s = E.compute_sim3_transform_robust(src, dst, 4, 4.0, 50, 4, "pts")
+        out = capsys.readouterr().out
+        assert f"Sim3 RANSAC on {len(src)} pts (threshold=4.0m, trials=50, min samples=4)" in out
+        assert f"best inlier count {len(src)}/{len(src)}" in out and f"scale={s:.4f}" in out
+        assert E.compute_sim3_transform_robust(src[:3], dst[:3], 4, 4.0, 50, 4, "pts")[0] is None
+        assert "too few input points (3 from pts), at least 4 needed" in capsys.readouterr().out
+        E.compute_sim3_transform(np.zeros((5, 3)), dst[:5])
+        assert "zero variance" in capsys.readouterr().out
+    finally:
+        E.VERBOSE = False
 
 
 def test_run_fusion_with_ground_truth_gnss(E, golden, tmp_path):
