@@ -544,7 +544,8 @@ def worker(args):
                 launch(hc)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            # (thread-local error mode: another thread of the process -- torch's RCCL watchdog polls events -- must not invalidate the capture)
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 for _ in range(steps):
                     launch(hc)
             torch.cuda.synchronize()
