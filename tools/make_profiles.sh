@@ -3,11 +3,17 @@
 #   1. kernel trace + stats of the DEFAULT bench command (python3 bench.py)
 #   2. PMC passes (separate runs: gpurun forbids mixing --pmc with trace domains) for HBM traffic and issue mix
 # Outputs under gpurun_out/profiles_raw/; tools/collect_profiles.py turns them into the committed profiles/*.
+# usage: tools/make_profiles.sh            every pass;
+#        tools/make_profiles.sh trace      only pass 1 again -- run it AFTER tools/collect_profiles.py has written profiles/rNN_traffic.json
+#                                          from the PMC passes, so that the committed bench line quotes that traffic / issue profile
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_raw
-rm -rf $OUT; mkdir -p $OUT
+if [ "$1" != "trace" ]; then rm -rf $OUT; fi
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+rm -rf $OUT/trace_bench_default
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench_default -- python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "trace failed"
+if [ "$1" = "trace" ]; then ls $OUT/trace_bench_default; exit 0; fi
 for wl in c2 c3; do
   for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
     n=$(echo $p | cut -d" " -f1)
