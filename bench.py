@@ -310,7 +310,7 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
     info["q15_rmse_vs_gnss_m_sample_mean"] = float(st[:, 3].nanmean().item())
     info["status_counts"] = {"had_outage": int((status & 1).ne(0).sum()), "rts_applied": int((status & 2).ne(0).sum()),
                              "sharp_turn": int((status & 4).ne(0).sum()), "ended_in_outage": int((status & 8).ne(0).sum()),
-                             "fit_none": int((status >> 8).ne(0).sum())}
+                             "fit_none": int(((status >> 8) & 1).ne(0).sum()), "fit_fallbacks": int(((status >> 8) & 16).ne(0).sum())}
     if world == 1:
         info["checksum_int64"] = int(local_sum.item())
         del batch, out
