@@ -529,17 +529,22 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
     bool cq_fresh = true;
     for (int64_t c0 = 0; c0 < N; c0 += 64) {
         const int64_t i = c0 + lane;
-        const bool active = i < N;
-        const bool is_init = (i == 0);
-        const bool stepping = active && !is_init;
         const int L = (int)((N - c0 < 64) ? (N - c0 - 1) : 63);          // last active lane of this chunk
+        // Lane predicates that depend on the lane index alone are formed as 64-bit masks on the SCALAR unit and handed to the lanes with
+        // inverse_ballot (a register copy): no compare / select / shift of the vector unit is spent on the outage structure.
+        const u64 act_mask = (L >= 63) ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L
+        const u64 init_m = (c0 == 0) ? 1ull : 0ull;                      // pose 0 sits in lane 0 of the first chunk
+        const u64 step_m = act_mask & ~init_m;
+        const bool active = __builtin_amdgcn_inverse_ballot_w64(act_mask);
+        const bool is_init = __builtin_amdgcn_inverse_ballot_w64(init_m);
+        const bool stepping = __builtin_amdgcn_inverse_ballot_w64(step_m);
         // ---- this chunk's poses were loaded one iteration ago; issue the loads of the NEXT 64 poses now so that their
         // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
         const ChunkIn in = nxt;
         nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);   // unconditional (clamped to the last row past the end): no branch between the loads and the arithmetic below
         const double t = in.t;
         const Vec3 p = in.p; const Quat q = in.q; const Vec3 z = in.z;
-        const bool vraw = in.v != 0;
+        const u64 vraw_m = __ballot(in.v != 0);
         // ---- calculate_relative_pose (ref :77-92) against the previous lane / the carry
         Quat r; const bool ok = quat_unit(q, r);
         const double t_pr = prev_lane(c_t, t);
@@ -547,10 +552,9 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         // (the previous pose's unit quaternion is only needed on the cold paths -- generic orientation, sharp-turn pairs -- and the
         // cross-lane move cannot be sunk there by the compiler: it is fetched inside those wave-uniform branches)
         const u64 ok_mask = __ballot(ok);
-        const bool ok_pr = (lane == 0) ? c_ok : (((ok_mask >> (lane - 1)) & 1ull) != 0ull);
+        const u64 both_m = ((ok_mask << 1) | (c_ok ? 1ull : 0ull)) & ok_mask;   // pose i-1 and pose i both have a valid quaternion
+        const bool both_ok = __builtin_amdgcn_inverse_ballot_w64(both_m);
         const double dt = fmax(1e-6, t - t_pr);                          // ref :865
-        const bool both_ok = ok_pr && ok;
-        const u64 act_mask = __ballot(active);
         // Fast path (every quaternion of the chunk and the carried one valid -- the normal case): the increments telescope,
         //   dq_first * ... * dq_i = conj(r_carry) * r_i   and   R(q_{i-1}) R(r_{i-1})^-1 = R(Cq),  Cq = q_carry * conj(r_carry),
         // so the orientation needs no scan and the predicted displacement is ONE rotation by the wave-uniform Cq
@@ -558,15 +562,19 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         const bool telescope = c_ok && ((ok_mask & act_mask) == act_mask);
         // (the generic path -- calculate_relative_pose per pose + a quaternion prefix product -- sits in ONE block further down, so
         // that the usual chunk runs from the loads to the scans without a branch)
-        // ---- GNSS gate (ref :867-869) and the outage structure of the chunk as ballots
-        const bool avail = stepping && vraw && !(isnan(z.x) || isnan(z.y) || isnan(z.z));
-        const bool av = is_init ? vraw : avail;                          // "gnss available" flag of pose i (pose 0: raw mask, :848)
-        const u64 a_mask = __ballot(active && av);
-        const bool ap = (lane == 0) ? (is_init ? true : c_prev_avail) : (((a_mask >> (lane - 1)) & 1ull) != 0ull);
-        const bool starts = active && !av && ap;                         // outage begins at this pose (ref :875-877; pose 0: :861)
-        const bool recovers = stepping && av && !ap;                     // ref :879
-        const bool outpair = stepping && !av && !ap;                     // poses i-1 and i both inside the outage
-        const u64 start_mask = __ballot(starts), rec_mask = __ballot(recovers), pair_mask = __ballot(outpair);
+        // ---- GNSS gate (ref :867-869) and the outage structure of the chunk, as masks
+        const u64 zfin_m = __ballot(!(isnan(z.x) || isnan(z.y) || isnan(z.z)));
+        const u64 avail_m = step_m & vraw_m & zfin_m;                    // the fix of pose i is used
+        const bool avail = __builtin_amdgcn_inverse_ballot_w64(avail_m);
+        const u64 av_m = (init_m & vraw_m) | avail_m;                    // "gnss available" flag of pose i (pose 0: raw mask, :848)
+        const bool av = __builtin_amdgcn_inverse_ballot_w64(av_m);
+        const u64 a_mask = act_mask & av_m;
+        const u64 ap_m = (a_mask << 1) | ((c0 == 0 || c_prev_avail) ? 1ull : 0ull);   // the flag of pose i-1 (lane 0: the carry; pose 0: true)
+        const u64 start_mask = act_mask & ~av_m & ap_m;                  // outage begins at this pose (ref :875-877; pose 0: :861)
+        const u64 rec_mask = step_m & av_m & ~ap_m;                      // ref :879
+        const u64 pair_mask = step_m & ~av_m & ~ap_m;                    // poses i-1 and i both inside the outage
+        const bool recovers = __builtin_amdgcn_inverse_ballot_w64(rec_mask);
+        const bool outpair = __builtin_amdgcn_inverse_ballot_w64(pair_mask);
         status |= (start_mask != 0ull) ? ST_HAD_OUTAGE : 0;
         // is_sharp_turn_in_segment (ref :808-826): pair (i-1, i) exceeds the yaw-rate threshold (or has a bad quaternion)
         u64 f_mask = 0ull;
