@@ -19,13 +19,14 @@ t0 = time.time()
 po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
 print(f"oracle {time.time() - t0:.1f} s; status histogram {np.bincount(sto, minlength=32)[:16].tolist()}", flush=True)
 worst = 0.0
-for name, layout, opt in (("wave (default)", 0, None), ("time-major via the wave kernel", 1, None), ("lane (time-major)", 1, ("lane_min_traj", 0))):
+blk = (("block (workgroup per trajectory)", 0, ("block_kernel", 1)),) if 64 < N <= 1024 else ()
+for name, layout, opt in (("wave (default)", 0, None), ("time-major via the wave kernel", 1, None), ("lane (time-major)", 1, ("lane_min_traj", 0))) + blk:
     batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
     if opt: B.context().set_option(*opt)
     try:
         p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
     finally:
-        if opt: B.context().set_option(opt[0], 32768)
+        if opt: B.context().set_option(opt[0], 32768 if opt[0] == "lane_min_traj" else -1)
     bad = np.nonzero(st != sto)[0]
     dp, dq = np.abs(p - po).max(), np.abs(q - qo).max()
     worst = max(worst, dp)
@@ -38,7 +39,7 @@ t0 = time.time()
 pr, qr, str_, Rr, tr, sr = orc.fuse_pipeline_batch(ts, pos, quat, gps, valid)
 ok = np.isfinite(pr).all(axis=(1, 2))
 print(f"oracle pipeline {time.time() - t0:.1f} s; {int((~ok).sum())} tracks without a fit", flush=True)
-for name, layout, opt in (("wave pipeline", 0, ("duo_kernel", 0)), ("two-wave pipeline", 0, ("duo_kernel", 1)), ("lane pipeline", 1, None)):
+for name, layout, opt in (("wave pipeline", 0, ("duo_kernel", 0)), ("two-wave pipeline", 0, ("duo_kernel", 1)), ("lane pipeline", 1, None)) + tuple((n_ + " pipeline", l_, o_) for n_, l_, o_ in blk):
     if opt and opt[0] == "duo_kernel" and opt[1] == 1 and N > 640:
         continue
     batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=layout)
@@ -47,7 +48,7 @@ for name, layout, opt in (("wave pipeline", 0, ("duo_kernel", 0)), ("two-wave pi
         out, R, t, s = B.fuse_pipeline_batch(batch)
         p, q, st = out.host_traj_major()
     finally:
-        if opt: B.context().set_option(opt[0], -1 if opt[0] == "duo_kernel" else 0)
+        if opt: B.context().set_option(opt[0], -1)
     assert (np.isfinite(p).all(axis=(1, 2)) == ok).all()
     bad = np.nonzero((st[ok] & 0xff) != (str_[ok] & 0xff))[0]
     dp, dq, ds = np.abs(p[ok] - pr[ok]).max(), np.abs(q[ok] - qr[ok]).max(), np.abs(s.cpu().numpy()[ok] - sr[ok]).max()
