@@ -88,6 +88,7 @@ SIGNATURES = {
     "gsf_sim3_ransac_mt_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_mt19937_seed_batch_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gsf_mt19937_choice_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gsf_mt19937_choice_bounded_batch_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "gsf_fuse_pipeline_robust_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
                                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_robust_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,

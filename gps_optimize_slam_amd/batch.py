@@ -240,9 +240,12 @@ def mt19937_choice_batch(state, n_population, trials, k):
     """sample_idx (B, trials, k) int32 = np.random.choice(n_population[b], k, replace=False) drawn `trials` times from stream b;
     `state` (B, 625) is advanced in place exactly as NumPy's generator would be."""
     B = state.shape[0]
+    # populations given on the host: their maximum lets the library take the chip-wide route for a few streams (gsf.h); a device
+    # tensor is passed as it is (no synchronising read-back)
+    n_max = 0 if (torch.is_tensor(n_population) and n_population.is_cuda) else int(max((int(v) for v in torch.as_tensor(n_population).reshape(-1)), default=0))
     n = torch.as_tensor(n_population, dtype=torch.int32).to(state.device).contiguous()
     idx = torch.empty((B, trials, k), dtype=torch.int32, device=state.device)
-    check(_lib.load().gsf_mt19937_choice_batch_dev(context().handle, _p(state), _p(n), B, int(trials), int(k), _p(idx)))
+    check(_lib.load().gsf_mt19937_choice_bounded_batch_dev(context().handle, _p(state), _p(n), n_max, B, int(trials), int(k), _p(idx)))
     return idx
 
 

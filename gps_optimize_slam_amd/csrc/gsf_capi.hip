@@ -39,6 +39,19 @@ int ensure_scratch(gsf_ctx* ctx, size_t bytes)
     return GSF_OK;
 }
 
+int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes)
+{
+    if (ctx->rng_scratch_bytes >= bytes) return GSF_OK;
+    if (ctx->rng_scratch) {
+        GSF_HIP(hipStreamSynchronize(ctx->stream));
+        GSF_HIP(hipFree(ctx->rng_scratch));
+        ctx->rng_scratch = nullptr; ctx->rng_scratch_bytes = 0;
+    }
+    GSF_HIP(hipMalloc(&ctx->rng_scratch, bytes + bytes / 4));
+    ctx->rng_scratch_bytes = bytes + bytes / 4;
+    return GSF_OK;
+}
+
 static int ensure_arena(void** p, size_t* have, size_t bytes, bool pinned, hipStream_t stream)
 {
     if (*have >= bytes) return GSF_OK;
@@ -163,6 +176,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
+    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
     // kernel-choice override for A/B runs of the whole test suite (the same meaning as gsf_set_option "block_kernel")
     if (const char* e = getenv("GSF_BLOCK_KERNEL")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->block_kernel = v; }
@@ -186,6 +200,7 @@ void gsf_destroy(gsf_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->rng_scratch) (void)hipFree(ctx->rng_scratch);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipEventDestroy(ctx->ev0);
@@ -212,6 +227,10 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     if (strcmp(key, "block_kernel") == 0) {
         if (value < -1 || value > 1) { set_error("gsf_set_option: block_kernel must be -1 (automatic), 0 (never) or 1 (whenever it applies)"); return GSF_ERR_INVALID_ARG; }
         ctx->block_kernel = (int)value; return GSF_OK;
+    }
+    if (strcmp(key, "tape_draws") == 0) {
+        if (value < -1 || value > 2 || value == 1) { set_error("gsf_set_option: tape_draws must be -1 (automatic: a few streams are drawn chip-wide), 0 (always one wave per stream) or 2 (tests: a tape cut short, so that the one-wave kernel takes over)"); return GSF_ERR_INVALID_ARG; }
+        ctx->tape_draws = (int)value; return GSF_OK;
     }
     if (strcmp(key, "duo_kernel") == 0) {
         if (value < -1 || value > 1) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 (one wave) or 1 (two-wave blocks)"); return GSF_ERR_INVALID_ARG; }

@@ -20,6 +20,11 @@ struct gsf_ctx {
     size_t stage_bytes;
     void* pinned;
     size_t pinned_bytes;
+    // tape, transition tables and swap partners of the chip-wide draws (gsf_rng_tape.hip); separate from `scratch`, whose layout the caller of
+    // launch_mt_choice may hold pointers into
+    void* rng_scratch;
+    size_t rng_scratch_bytes;
+    int tape_draws;        // chip-wide draws for a few streams (gsf_set_option "tape_draws"): -1 automatic, 0 never, 2 tests (tape cut short)
     int ekf_variant;       // reserved tuning knob (gsf_set_option "ekf_variant"); 0 = default
     int synth_variant;     // synthetic workload (gsf_set_option "synth_variant"): 0 = white SLAM noise (default), 1 = SURVEY 8d's random-walk drift
     int block_kernel;      // workgroup-per-trajectory kernel for 64 < N <= 1024 (gsf_set_option "block_kernel"): -1 automatic, 0 never, 1 always
@@ -55,6 +60,7 @@ struct Idx {
 };
 
 int ensure_scratch(gsf_ctx* ctx, size_t bytes);
+int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes);
 
 // wave-per-trajectory K4 / fused pipeline for the trajectory-major layout (gsf_ekf_wave.hip)
 int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
@@ -76,6 +82,10 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
 // legacy MT19937 state; n_b = counts[b] (int32) -- asynchronous on the context's stream
 int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx,
                      int32_t n_max /* largest counts[b] if the host knows it, else 0 */);
+// the same draws for a few streams, spread over the chip (gsf_rng_tape.hip); launch_mt_choice picks it when mt_tape_applies
+bool mt_tape_applies(const gsf_ctx* ctx, int64_t B, int32_t trials, int32_t k, int32_t n_max);
+int launch_mt_tape(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx, int32_t n_max,
+                   const int32_t** done_flags, int* done_stride);
 
 // Staging of the host-pointer entry points.  ONE grow-only device arena per context plus a pinned host mirror of it: the
 // inputs of a call are packed into the mirror and cross PCIe in one hipMemcpyAsync, the outputs come back in one, and no call

@@ -36,12 +36,14 @@ __global__ __launch_bounds__(64) void mt_seed_kernel(const uint32_t* __restrict_
 
 // sample_idx[b][trial][0..k) = permutation(n_b)[:k] for `trials` consecutive trials of stream b; state advanced exactly as NumPy's.
 __global__ __launch_bounds__(64) void mt_choice_kernel(uint32_t* __restrict__ state, const int32_t* __restrict__ counts, int trials, int kk,
-                                                       int32_t* __restrict__ sample_idx, int jseq_bytes)
+                                                       int32_t* __restrict__ sample_idx, int jseq_bytes, const int32_t* __restrict__ done_flags,
+                                                       int done_stride)
 {
     __shared__ uint32_t mt[MT_N + 1];
     extern __shared__ uint16_t jseq[];
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
+    if (done_flags && done_flags[b * done_stride]) return;               // drawn by the chip-wide route (gsf_rng_tape.hip)
     const int n = counts[b];
     int32_t* out = sample_idx + (size_t)b * (size_t)trials * (size_t)kk;
     if (n < kk || n < 1 || n > CHOICE_MAX_N) {                           // the reference returns before drawing (ref :395-397): stream untouched
@@ -62,12 +64,20 @@ __global__ __launch_bounds__(64) void mt_choice_kernel(uint32_t* __restrict__ st
 namespace gsf {
 int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx, int32_t n_max)
 {
+    // a few streams of moderate size: the chip-wide route draws them; this kernel then only serves the streams that route left (its
+    // header says which: sets outside its range, or a tape that ran short)
+    const int32_t* done_flags = nullptr; int done_stride = 0;
+    if (n_max > 0 && mt_tape_applies(ctx, B, trials, k, n_max)) {
+        const int rc = launch_mt_tape(ctx, state, counts, B, trials, k, sample_idx, n_max, &done_flags, &done_stride);
+        if (rc) return rc;
+    }
     // LDS for the swap partners of up to 64 buffered trials of the LARGEST set (n_max rows; 0 = unknown): as little as the sets need,
     // so that four streams share a CU when they can
     int bytes = CHOICE_LDS_JSEQ_MAX;
     if (n_max > 0 && (int64_t)n_max * 2 * 64 <= CHOICE_LDS_JSEQ_AIM) bytes = n_max * 2 * 64;
     else if (n_max > 0 && (int64_t)n_max * 2 * 8 <= CHOICE_LDS_JSEQ_AIM) bytes = CHOICE_LDS_JSEQ_AIM;
-    hipLaunchKernelGGL(mt_choice_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, state, counts, (int)trials, (int)k, sample_idx, bytes);
+    hipLaunchKernelGGL(mt_choice_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, state, counts, (int)trials, (int)k, sample_idx, bytes,
+                       done_flags, done_stride);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -93,6 +103,16 @@ int gsf_mt19937_choice_batch_dev(gsf_ctx* ctx, uint32_t* state, const int32_t* n
     GSF_REQUIRE(state && n_population && sample_idx, "NULL array");
     GSF_HIP(hipSetDevice(ctx->device));
     return launch_mt_choice(ctx, state, n_population, B, trials, k, sample_idx, 0);
+}
+
+int gsf_mt19937_choice_bounded_batch_dev(gsf_ctx* ctx, uint32_t* state, const int32_t* n_population, int32_t n_max, int64_t B, int32_t trials,
+                                         int32_t k, int32_t* sample_idx)
+{
+    GSF_REQUIRE(ctx && B >= 0 && B <= 0x7fffffff && trials >= 0 && k >= 1 && k <= 64 && n_max >= 0, "bad arguments");
+    if (B == 0 || trials == 0) return GSF_OK;
+    GSF_REQUIRE(state && n_population && sample_idx, "NULL array");
+    GSF_HIP(hipSetDevice(ctx->device));
+    return launch_mt_choice(ctx, state, n_population, B, trials, k, sample_idx, n_max);
 }
 
 }  // extern "C"

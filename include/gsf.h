@@ -99,6 +99,10 @@ GSF_API int gsf_synchronize(gsf_ctx *ctx);
      "duo_kernel"     -1 automatic (default) / 0 never / 1 always: two-wave build of the fused pipeline for small batches of short tracks
      "lane_min_traj"  time-major batches with fewer trajectories than this (default 32768) are transposed and run by the
                       wave-per-trajectory kernel; 0 = always the lane-per-trajectory kernel
+     "block_kernel"   -1 / 0 never (what -1 means today) / 1 whenever it applies: workgroup-per-trajectory EKF kernel for 64 < N <= 1024
+     "tape_draws"     -1 automatic (default): up to 16 MT19937 streams of <= 2040 rows are drawn chip-wide (csrc/gsf_rng_tape.hip) /
+                      0 always one wave per stream / 2 tests only (a tape cut short: the one-wave kernel must take over)
+     "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift
      "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
 /* opens / closes a HIP-event bracket on the context's stream; gsf_timer_stop returns the elapsed ms */
@@ -221,10 +225,17 @@ GSF_API int gsf_sim3_ransac_mt_batch(gsf_ctx *ctx, const double *src, const doub
    gsf_mt19937_choice_batch_dev: sample_idx[b][trial][0..k) = RandomState.permutation(n_population[b])[:k] for `trials`
    consecutive trials of stream b (what np.random.choice(n, k, replace=False) draws; also scikit-learn's
    sample_without_replacement for 0.01 < k/n < 0.99), the state advanced exactly as NumPy advances it.  Streams with
-   n_population[b] < k are left untouched (the reference returns before drawing, :395-397).  n_population[b] <= 28000, k <= 64. */
+   n_population[b] < k are left untouched (the reference returns before drawing, :395-397).  n_population[b] <= 28000, k <= 64.
+   gsf_mt19937_choice_bounded_batch_dev: the same, with n_max >= every n_population[b] known to the HOST (0 = unknown).  The
+   populations live in device memory, so only with this bound can the library size the workspace of the chip-wide route
+   (csrc/gsf_rng_tape.hip): up to 16 streams of n_max <= 2040 are then drawn by thousands of waves instead of one wave per stream
+   (the reference's own case is ONE stream); results and final states are identical either way.  A stream whose population
+   exceeds n_max is drawn by the one-wave route. */
 GSF_API int gsf_mt19937_seed_batch_dev(gsf_ctx *ctx, const uint32_t *seeds, int64_t B, uint32_t *state);
 GSF_API int gsf_mt19937_choice_batch_dev(gsf_ctx *ctx, uint32_t *state, const int32_t *n_population, int64_t B, int32_t trials,
                                          int32_t k, int32_t *sample_idx);
+GSF_API int gsf_mt19937_choice_bounded_batch_dev(gsf_ctx *ctx, uint32_t *state, const int32_t *n_population, int32_t n_max, int64_t B,
+                                                 int32_t trials, int32_t k, int32_t *sample_idx);
 
 /* ---- K3: apply Sim3 (transform_trajectory, EKFGPSSLAM.py:461-467) -------------------------- */
 /* pos[total][3], quat[total][4]; per-trajectory R[B][9], t[B][3], s[B].  A zero-norm quaternion (SciPy raises

@@ -1229,10 +1229,63 @@ def test_device_mt19937_choice_matches_numpy(B):
     assert np.random.random() == after
 
 
-def test_robust_pipeline_chain_vs_oracle(B, orc):
+def test_chip_wide_draws_match_numpy(B):
+    """The chip-wide route of the draws (csrc/gsf_rng_tape.hip: tape -> transition tables -> composed walk -> replay -> trace) against
+    NumPy: sample sets trial by trial and the generator state afterwards, for populations from 2 to 2040, k up to 64, entries at
+    every kind of block position, several streams per call; the same cases with the tape cut short (the one-wave kernel must take
+    over, nothing half-written) and a population above the bound the caller gave (that stream alone goes the one-wave way)."""
+    import ctypes
+    import torch
+    from gps_optimize_slam_amd import _lib
+
+    def numpy_side(seed, skip, n, trials, k):
+        np.random.seed(seed)
+        if skip: np.random.random(skip)
+        st = B.mt19937_from_numpy()
+        ref = np.stack([np.random.choice(n, k, replace=False) for _ in range(trials)]) if n >= k else None
+        key, pos = np.random.get_state()[1:3]
+        return st, ref, key.copy(), int(pos)
+
+    cases = [((7,), (271,), 1000, 4, 0), ((11,), (271,), 700, 4, 311), ((3, 4, 5), (271, 150, 64), 400, 6, 17),
+             ((21,), (2,), 20000, 1, 5), ((22,), (3,), 9000, 2, 0), ((23,), (65,), 700, 4, 1), ((24,), (129,), 300, 64, 2),
+             ((25,), (2040,), 40, 4, 0), ((26,), (1730,), 60, 8, 623), ((30, 31, 32, 33), (300, 3, 300, 1000), 90, 4, 9)]
+    try:
+        for mode in (-1, 2):                                            # 2 = the tape ends at 90 % of the expected consumption
+            B.context().set_option("tape_draws", mode)
+            for seeds, ns, trials, k, skip in cases:
+                sides = [numpy_side(s_, skip, n, trials, k) for s_, n in zip(seeds, ns)]
+                st = torch.cat([x[0] for x in sides], dim=0).contiguous()
+                idx = B.mt19937_choice_batch(st, list(ns), trials, k).cpu().numpy()
+                got = st.cpu().numpy().view(np.uint32)
+                for b_, (_, ref, key, pos) in enumerate(sides):
+                    if ref is not None:
+                        np.testing.assert_array_equal(idx[b_], ref, err_msg=f"mode {mode} case {seeds} stream {b_}")
+                    np.testing.assert_array_equal(got[b_, :624], key, err_msg=f"state, mode {mode} case {seeds} stream {b_}")
+                    assert int(got[b_, 624]) == pos
+        # a bound smaller than one population (raw C ABI: the Python wrapper always passes the true maximum)
+        B.context().set_option("tape_draws", -1)
+        sides = [numpy_side(41, 0, 300, 200, 4), numpy_side(42, 0, 400, 200, 4)]
+        st = torch.cat([x[0] for x in sides], dim=0).contiguous()
+        npop = torch.tensor([300, 400], dtype=torch.int32, device="cuda")
+        idx = torch.empty((2, 200, 4), dtype=torch.int32, device="cuda")
+        vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        rc = _lib.load().gsf_mt19937_choice_bounded_batch_dev(B.context().handle, vp(st), vp(npop), 300, 2, 200, 4, vp(idx))
+        assert rc == 0
+        torch.cuda.synchronize()
+        for b_, (_, ref, key, pos) in enumerate(sides):
+            np.testing.assert_array_equal(idx[b_].cpu().numpy(), ref)
+            got = st[b_].cpu().numpy().view(np.uint32)
+            np.testing.assert_array_equal(got[:624], key); assert int(got[624]) == pos
+    finally:
+        B.context().set_option("tape_draws", -1)
+
+
+@pytest.mark.parametrize("nb", [24, 8])
+def test_robust_pipeline_chain_vs_oracle(B, orc, nb):
     """RANSAC -> final fit -> Sim3 of pose 0 -> EKF+RTS as ONE device chain with the draws generated on the device, against the
-    oracle fed with NumPy's own draws for the same seeds: identical inlier masks / counts, R, t, s and fused poses inside the gate."""
-    nb, N = 24, 271
+    oracle fed with NumPy's own draws for the same seeds: identical inlier masks / counts, R, t, s and fused poses inside the gate.
+    24 streams are drawn one wave per stream, 8 by the chip-wide route (csrc/gsf_rng_tape.hip), the empty set among them by neither."""
+    N = 271
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=41)
     h = batch.host_traj_major()
     # outliers: a few GNSS fixes thrown far off so that the robust fit differs from the plain one
