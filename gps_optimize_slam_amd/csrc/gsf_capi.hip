@@ -176,7 +176,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
-    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1;
+    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
     // kernel-choice override for A/B runs of the whole test suite (the same meaning as gsf_set_option "block_kernel")
     if (const char* e = getenv("GSF_BLOCK_KERNEL")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->block_kernel = v; }
@@ -186,6 +186,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     }
     hipError_t e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc(&c->small_scratch, 512);
     if (e != hipSuccess) { delete c; return fail_hip(e, "hipEventCreate"); }
     *out = c;
     return GSF_OK;
@@ -201,6 +202,7 @@ void gsf_destroy(gsf_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->rng_scratch) (void)hipFree(ctx->rng_scratch);
+    if (ctx->small_scratch) (void)hipFree(ctx->small_scratch);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipEventDestroy(ctx->ev0);

@@ -14,6 +14,7 @@
 //   3. writes the inlier mask of the accepted model.
 // One 128-thread block per problem; rows of a problem are contiguous ([total] arrays + int64 offsets[P+1]).
 #include "gsf_mt19937.hpp"
+#include "gsf_wave_common.hpp"   // wave_sum on DPP (no LDS round trips)
 
 using namespace gsf;
 
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     __shared__ int sh_nin[CH_MAX_TRIALS];
     __shared__ double sh_score[CH_MAX_TRIALS];
     __shared__ int32_t sh_end[CH_MAX_TRIALS];
+    __shared__ PolyModel sh_model[64];                                    // models of the batch being scored (batches are 8, 16, 32, then 64 trials)
     extern __shared__ uint16_t dyn[];                                     // [jseq_elems] swap partners, then int32 idx[max_trials * ms]
     uint16_t* jseq = dyn;
     int32_t* sh_idx = (int32_t*)(dyn + ((jseq_elems + 1) & ~1));
@@ -331,15 +333,43 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             // ~600 dependent instructions of the stream walk.  The walk itself runs redundantly on every lane (wave-uniform state).
             int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0;
             double best_score = -INFINITY, max_tr = (double)max_trials;
-            for (int tbn = 8; (double)ntr < max_tr; tbn *= 2) {
+            for (int tbn = 4; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
                 const int nb = (max_trials - drawn < tbn) ? (max_trials - drawn) : tbn;
                 if (nb <= 0) break;
                 mt_draw_choice(mt, pos_mt, n, nb, ms, jseq, jseq_elems, sh_idx + (size_t)drawn * ms, sh_end + drawn, lane);
+                // models: a lane per trial (at most 32 of them work); scores: the whole wave over the ROWS of one trial at a time -- a batch
+                // is 8-32 trials of ~150 rows, and a lane walking all rows of its trial alone was 44 of a window-axis's 85 us
                 for (int tau = lane; tau < nb; tau += 64) {
-                    int c; double sc;
-                    score_trial(tp, yp, 3, n, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, thr, c, sc);
-                    sh_nin[drawn + tau] = c; sh_score[drawn + tau] = sc;
+                    sh_model[tau] = fit_subset(tp, yp, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, 3);
                     sh_end[drawn + tau] += raw_base;                          // outputs consumed since the window-axis start
+                }
+                __syncthreads();
+                for (int tau = 0; tau < nb; ++tau) {
+                    const PolyModel m = sh_model[tau];
+                    int cnt = 0; double sy = 0.0;
+                    for (int i0 = 0; i0 < n; i0 += 64) {
+                        const int i = i0 + lane;
+                        const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
+                        const bool in = i < n && fabs(yi - poly_predict(m, degree, tp[i < n ? i : 0])) <= thr;
+                        cnt += __popcll(__ballot(in));
+                        sy += in ? yi : 0.0;
+                    }
+                    double score = NAN;
+                    if (cnt >= 2) {                                           // wave-uniform
+                        const double ym = wave_sum(sy) / (double)cnt;
+                        double ss_res = 0.0, ss_tot = 0.0;
+                        for (int i0 = 0; i0 < n; i0 += 64) {
+                            const int i = i0 + lane;
+                            const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
+                            const double pr = poly_predict(m, degree, tp[i < n ? i : 0]);
+                            const bool in = i < n && fabs(yi - pr) <= thr;
+                            ss_res += in ? (yi - pr) * (yi - pr) : 0.0;
+                            ss_tot += in ? (yi - ym) * (yi - ym) : 0.0;
+                        }
+                        ss_res = wave_sum(ss_res); ss_tot = wave_sum(ss_tot);
+                        score = ss_tot != 0.0 ? 1.0 - ss_res / ss_tot : (ss_res == 0.0 ? 1.0 : 0.0);
+                    }
+                    if (lane == 0) { sh_nin[drawn + tau] = cnt; sh_score[drawn + tau] = score; }
                 }
                 __syncthreads();
                 drawn += nb;
@@ -429,7 +459,7 @@ int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos
     if (B == 0) return GSF_OK;
     GSF_REQUIRE(t && pos, "NULL rows");
     GSF_HIP(hipSetDevice(ctx->device));
-    // dynamic LDS (40 KB next to 21 KB of static arrays): the sample sets of one window-axis, then the swap partners of as many trials
+    // dynamic LDS (40 KB next to 23 KB of static arrays): the sample sets of one window-axis, then the swap partners of as many trials
     // as the rest allows (at least one trial's worth)
     const size_t idx_bytes = (size_t)max_trials * (size_t)min_samples * 4;
     GSF_REQUIRE(idx_bytes + 2 * (size_t)max_window_rows + 4 <= 40 * 1024, "max_trials x min_samples / window length exceed the device sampler's LDS budget");

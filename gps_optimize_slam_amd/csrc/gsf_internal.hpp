@@ -22,6 +22,7 @@ struct gsf_ctx {
     size_t pinned_bytes;
     // tape, transition tables and swap partners of the chip-wide draws (gsf_rng_tape.hip); separate from `scratch`, whose layout the caller of
     // launch_mt_choice may hold pointers into
+    void* small_scratch;   // 512 B: arg-max keys of the split K2b launch (gsf_sim3.hip: up to 32 sets x 16 B)
     void* rng_scratch;
     size_t rng_scratch_bytes;
     int tape_draws;        // chip-wide draws for a few streams (gsf_set_option "tape_draws"): -1 automatic, 0 never, 2 tests (tape cut short)

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(64) void windows_finalize_kernel(const double* __re
 
 // ------------------------------------------------------------------------------------------------
 constexpr int RANSAC_THREADS = 256;
+constexpr int RANSAC_SPLIT_MAX_SETS = 32;   // up to this many sets, a set's hypotheses go to many single-wave blocks (ransac_scan_kernel)
 constexpr int RANSAC_MAX_SAMPLES = 4096;    // the kernel walks a sample set row by row: no structural limit (a sanity bound)
 
 __device__ __forceinline__ double block_sum(double v, double* sh, int tid)
@@ -470,37 +471,15 @@ __device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const 
     return within(resid2(src, dst, r, R, t, s), thr);
 }
 
-__global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
-    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
-    const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
-    double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
-    int32_t* __restrict__ n_inliers)
+// hypotheses tr = first, first + step, ... < last of set b (ref :404-414): this thread's best as a key, highest count first, then the
+// LOWEST trial (strict > keeps the first, :413); key 0 = no usable hypothesis
+__device__ __forceinline__ unsigned long long ransac_scan_trials(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0, int64_t n,
+                                                                 const int32_t* __restrict__ my_idx, int first, int last, int step, int ms, double thr,
+                                                                 bool& bad_index)
 {
-    __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
-    __shared__ double sh_fit[13];
-    __shared__ double sh_red[RANSAC_THREADS / 64];
-    __shared__ int sh_cnt[RANSAC_THREADS / 64];
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    // set b = rows offsets[b] .. offsets[b] + n; n = counts[b] when the sets sit in fixed-stride slots (robust pipeline), else the gap
-    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
-    auto write_none = [&](int32_t best) {
-        if (tid == 0) {
-            for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
-            tout[b * 3] = tout[b * 3 + 1] = tout[b * 3 + 2] = NAN; sout[b] = NAN;
-            status[b] = SIM3_NONE; n_inliers[b] = best;
-        }
-    };
-    if (n < ms) {                                                            // ref :395-397
-        for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
-        write_none(-1);
-        return;
-    }
-    // ---- hypotheses: one per thread, strided over the trials (ref :404-414)
-    const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
+    const int64_t i1 = i0 + n;
     long long best_cnt = -1; int best_trial = 0x7fffffff;
-    bool bad_index = false;
-    for (int tr = tid; tr < trials; tr += RANSAC_THREADS) {
+    for (int tr = first; tr < last; tr += step) {
         double R[9], t[3], s;
         // caller-fed row indices are validated: a sample naming a row outside [0, n) is skipped like a degenerate one and flagged
         bool in_range = true;
@@ -521,24 +500,40 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
         for (; r < i1; ++r) cnt += is_inlier(src, dst, r, R, t, s, thr) ? 1 : 0;
         if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
     }
-    // block arg-max: highest count, then lowest trial index
-    unsigned long long key = ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+    return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long key)
+{
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long other = __shfl_xor(key, o, 64);
+        const unsigned long long other = __shfl_xor(key, o, 64);
         key = other > key ? other : key;
     }
-    const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
-    if ((tid & 63) == 0) sh_key[tid >> 6] = key;
-    __syncthreads();
-    key = sh_key[0];
-#pragma unroll
-    for (int w = 1; w < RANSAC_THREADS / 64; ++w) key = sh_key[w] > key ? sh_key[w] : key;
+    return key;
+}
+__device__ __forceinline__ void ransac_write_none(int64_t b, int32_t best, int tid, double* __restrict__ Rout, double* __restrict__ tout,
+                                                  double* __restrict__ sout, int32_t* __restrict__ status, int32_t* __restrict__ n_inliers)
+{
+    if (tid == 0) {
+        for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
+        tout[b * 3] = tout[b * 3 + 1] = tout[b * 3 + 2] = NAN; sout[b] = NAN;
+        status[b] = SIM3_NONE; n_inliers[b] = best;
+    }
+}
+// the winner's mask and the final fit on its inliers (ref :415-421), by a whole RANSAC_THREADS block; key = block-uniform arg-max
+__device__ __forceinline__ void ransac_finish(int64_t b, unsigned long long key, bool any_bad, const double* __restrict__ src,
+                                              const double* __restrict__ dst, int64_t i0, int64_t n, const int32_t* __restrict__ my_idx, int ms,
+                                              double thr, int min_inliers, double* __restrict__ Rout, double* __restrict__ tout,
+                                              double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
+                                              int32_t* __restrict__ n_inliers, double* sh_fit, double* sh_red)
+{
+    const int tid = threadIdx.x;
+    const int64_t i1 = i0 + n;
     const long long win_cnt = (long long)(key >> 32) - 1;
     const int win_trial = 0x7fffffff - (int)(key & 0xffffffffull);
     if (win_cnt < 0) {                                                       // every trial was degenerate
         for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
-        write_none(-1);
+        ransac_write_none(b, -1, tid, Rout, tout, sout, status, n_inliers);
         return;
     }
     // ---- winner's mask
@@ -555,7 +550,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     tw[0] = sh_fit[9]; tw[1] = sh_fit[10]; tw[2] = sh_fit[11];
     const double sw = sh_fit[12];
     for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = is_inlier(src, dst, i, Rw, tw, sw, thr) ? 1 : 0;
-    if (win_cnt < (long long)min_inliers) { write_none((int32_t)win_cnt); return; }   // ref :416-418
+    if (win_cnt < (long long)min_inliers) { ransac_write_none(b, (int32_t)win_cnt, tid, Rout, tout, sout, status, n_inliers); return; }   // ref :416-418
     __syncthreads();                                                         // mask visible block-wide (same CU)
     // ---- final fit on the inliers (ref :420-421): block-wide two-pass moments
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
@@ -592,7 +587,78 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
         tout[b * 3] = t[0]; tout[b * 3 + 1] = t[1]; tout[b * 3 + 2] = t[2]; sout[b] = s;
         status[b] = st | ((any_bad && st != SIM3_NONE) ? SIM3_FLAG_BAD_INDEX : 0); n_inliers[b] = (int32_t)win_cnt;
     }
-    (void)sh_cnt;
+}
+
+// One block per set: hypotheses strided over the threads, block arg-max, finish.
+__global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
+    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
+    const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
+    double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
+    int32_t* __restrict__ n_inliers)
+{
+    __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
+    __shared__ double sh_fit[13];
+    __shared__ double sh_red[RANSAC_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    // set b = rows offsets[b] .. offsets[b] + n; n = counts[b] when the sets sit in fixed-stride slots (robust pipeline), else the gap
+    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
+    if (n < ms) {                                                            // ref :395-397
+        for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
+        ransac_write_none(b, -1, tid, Rout, tout, sout, status, n_inliers);
+        return;
+    }
+    const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
+    bool bad_index = false;
+    unsigned long long key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+    const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
+    if ((tid & 63) == 0) sh_key[tid >> 6] = key;
+    __syncthreads();
+    key = sh_key[0];
+#pragma unroll
+    for (int w = 1; w < RANSAC_THREADS / 64; ++w) key = sh_key[w] > key ? sh_key[w] : key;
+    ransac_finish(b, key, any_bad, src, dst, i0, n, my_idx, ms, thr, min_inliers, Rout, tout, sout, status, inlier_mask, n_inliers, sh_fit, sh_red);
+}
+
+// FEW sets (the reference's own case is one): the hypotheses of a set are spread over many single-wave blocks, a hypothesis per lane,
+// and meet in keys[b] = { arg-max key, bad-index flag } (zeroed by the launcher); ransac_finish_kernel then does what the tail of
+// ransac_batch_kernel does.  One set x 1 000 trials: 130 us on one CU -> two launches of ~25 and ~8 us.
+__global__ __launch_bounds__(64) void ransac_scan_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ sample_idx, int trials, int ms,
+                                                         double thr, unsigned long long* __restrict__ keys)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
+    if (n < ms) return;
+    const int tr = blockIdx.x * 64 + threadIdx.x;
+    bool bad_index = false;
+    const unsigned long long key = wave_max_key(ransac_scan_trials(src, dst, i0, n, sample_idx + (size_t)b * (size_t)trials * (size_t)ms, tr,
+                                                                   tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
+    const bool any_bad = __ballot(bad_index) != 0ull;
+    if (threadIdx.x == 0) {
+        if (key) atomicMax(&keys[b * 2], key);
+        if (any_bad) atomicOr(&keys[b * 2 + 1], 1ull);
+    }
+}
+__global__ __launch_bounds__(RANSAC_THREADS) void ransac_finish_kernel(
+    const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
+    const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, const unsigned long long* __restrict__ keys,
+    double* __restrict__ Rout, double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status,
+    uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_inliers)
+{
+    __shared__ double sh_fit[13];
+    __shared__ double sh_red[RANSAC_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
+    if (n < ms) {                                                            // ref :395-397
+        for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
+        ransac_write_none(b, -1, tid, Rout, tout, sout, status, n_inliers);
+        return;
+    }
+    // a key of 0 (no usable hypothesis anywhere) reads as count -1, like the one-block kernel's
+    ransac_finish(b, keys[b * 2], keys[b * 2 + 1] != 0ull, src, dst, i0, n, sample_idx + (size_t)b * (size_t)trials * (size_t)ms, ms, thr, min_inliers, Rout,
+                  tout, sout, status, inlier_mask, n_inliers, sh_fit, sh_red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,6 +696,17 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
                        const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
                        double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
 {
+    if (B <= RANSAC_SPLIT_MAX_SETS && trials >= 256) {
+        // few sets: hypotheses spread over the chip, then one finishing block per set
+        unsigned long long* keys = (unsigned long long*)ctx->small_scratch;
+        GSF_HIP(hipMemsetAsync(keys, 0, (size_t)B * 16, ctx->stream));
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
+                           sample_idx, (int)trials, (int)min_samples, thr, keys);
+        hipLaunchKernelGGL(ransac_finish_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
+                           (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers);
+        GSF_HIP(hipGetLastError());
+        return GSF_OK;
+    }
     hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
                        (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers);
     GSF_HIP(hipGetLastError());
