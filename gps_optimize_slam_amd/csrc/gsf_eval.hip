@@ -81,6 +81,110 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
     }
 }
 
+// The same metric for tracks of up to EVAL_LDS_MAX_N poses (every BASELINE config): the candidate set is compacted into LDS once
+// (coordinates, original index, later the errors), and the M x M pair work -- nearest fix, then the rank count of the median -- is
+// spread evenly: S adjacent lanes share a query (S = a power of two with M*S ~ 2 000 work items for the 256 threads), each walking
+// every S-th candidate, and meet in a DPP-free xor butterfly.  min / counts are order-independent, so the results are the
+// one-thread-per-query kernel's bit for bit; the sums of the mean / RMSE keep that kernel's order of partial sums only up to the
+// last digits (gate 1e-9 m in the tests).  271 poses: 111 -> ~25 us for one track, 139 -> ~60 us for 1 000.
+constexpr int EVAL_LDS_MAX_N = 1536;
+__global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const double* __restrict__ ts, const double* __restrict__ traj,
+                                                                       const double* __restrict__ gps, const uint8_t* __restrict__ valid,
+                                                                       int64_t N, double skip, double* __restrict__ stats,
+                                                                       double* __restrict__ errors)
+{
+    extern __shared__ double dynl[];                                     // cx[N], cy[N], cz[N], err[N], then int32 qidx[N]
+    __shared__ double sh[EVAL_THREADS / 64];
+    __shared__ double sh_med[2];
+    __shared__ int sh_cnt[EVAL_THREADS / 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = (int)N;
+    const int64_t b = blockIdx.x;
+    const double* t = ts + b * N; const double* p = traj + b * N * 3; const double* g = gps + b * N * 3;
+    const uint8_t* v = valid + b * N;
+    double* e = errors + b * N;
+    double* cx = dynl; double* cy = cx + n; double* cz = cy + n; double* cerr = cz + n;
+    int32_t* qidx = (int32_t*)(cerr + n);
+    const double thr = t[0] + skip;                                      // :1018
+    // ---- candidate / query set (:1016-1021), compacted in row order
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += EVAL_THREADS) {
+        const int i = i0 + tid;
+        double gx = 0.0, gy = 0.0, gz = 0.0;
+        bool in = false;
+        if (i < n) {
+            gx = g[(int64_t)i * 3]; gy = g[(int64_t)i * 3 + 1]; gz = g[(int64_t)i * 3 + 2];
+            in = v[i] != 0 && t[i] > thr && !(isnan(gx) || isnan(gy) || isnan(gz));
+            if (!in) e[i] = NAN;
+        }
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) sh_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += sh_cnt[w];
+        const int at = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (in) { cx[at] = gx; cy[at] = gy; cz[at] = gz; qidx[at] = i; }
+        base += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+        __syncthreads();
+    }
+    const int M = base;                                                  // block-uniform
+    int S = 1;
+    while (S < 64 && M * (S * 2) <= 2048) S *= 2;
+    const int part = tid & (S - 1);
+    // ---- nearest fix of every query (:1030-1031)
+    double cnt = 0.0, sum = 0.0, sum2 = 0.0;
+    for (int it0 = 0; it0 < M * S; it0 += EVAL_THREADS) {
+        const int q = (it0 + tid) / S;                                   // S divides 64 and 256: the S lanes of a query sit side by side in one wave
+        const bool live = q < M;
+        const int row = live ? qidx[q] : 0;
+        const double x = p[(int64_t)row * 3], y = p[(int64_t)row * 3 + 1], z = p[(int64_t)row * 3 + 2];
+        double best = INFINITY;
+        if (live) {
+#pragma unroll 4
+            for (int k = part; k < M; k += S) {
+                const double dx = x - cx[k], dy = y - cy[k], dz = z - cz[k];
+                best = fmin(best, dx * dx + dy * dy + dz * dz);
+            }
+        }
+        for (int o = 1; o < S; o <<= 1) best = fmin(best, __shfl_xor(best, o, 64));
+        if (live && part == 0) {
+            const double err = sqrt(best);
+            cerr[q] = err; e[row] = err;
+            cnt += 1.0; sum += err; sum2 += err * err;
+        }
+    }
+    const double Mf = block_reduce_sum(cnt, sh, tid);
+    const double S1 = block_reduce_sum(sum, sh, tid);
+    const double S2 = block_reduce_sum(sum2, sh, tid);
+    if (tid == 0) { sh_med[0] = NAN; sh_med[1] = NAN; }
+    __syncthreads();                                                     // cerr[] complete
+    // ---- np.median: the two middle order statistics by rank count (ties broken by row order)
+    if (M > 0) {
+        const int k_lo = (M - 1) / 2, k_hi = M / 2;
+        for (int it0 = 0; it0 < M * S; it0 += EVAL_THREADS) {
+            const int q = (it0 + tid) / S;
+            const bool live = q < M;
+            const double ei = live ? cerr[q] : 0.0;
+            int rank = 0;
+            if (live) {
+#pragma unroll 4
+                for (int k = part; k < M; k += S) { const double ej = cerr[k]; rank += (ej < ei || (ej == ei && k < q)) ? 1 : 0; }
+            }
+            for (int o = 1; o < S; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (live && part == 0 && !isnan(ei)) {
+                if (rank == k_lo) sh_med[0] = ei;
+                if (rank == k_hi) sh_med[1] = ei;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        stats[b * 4] = Mf;
+        stats[b * 4 + 1] = M > 0 ? S1 / Mf : NAN;
+        stats[b * 4 + 2] = M > 0 ? 0.5 * (sh_med[0] + sh_med[1]) : NAN;
+        stats[b * 4 + 3] = M > 0 ? sqrt(S2 / Mf) : NAN;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -92,7 +196,11 @@ int gsf_eval_errors_batch_dev(gsf_ctx* ctx, const double* ts, const double* traj
     if (B == 0 || N == 0) return GSF_OK;
     GSF_REQUIRE(ts && traj_pos && aligned_gps && valid && stats && errors, "NULL array");
     GSF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(eval_errors_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), 0, ctx->stream, ts, traj_pos, aligned_gps, valid, N, skip_seconds, stats, errors);
+    if (N <= EVAL_LDS_MAX_N)
+        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, traj_pos, aligned_gps, valid, N,
+                           skip_seconds, stats, errors);
+    else
+        hipLaunchKernelGGL(eval_errors_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), 0, ctx->stream, ts, traj_pos, aligned_gps, valid, N, skip_seconds, stats, errors);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
