@@ -84,6 +84,7 @@ SIGNATURES = {
     "gsf_sim3_umeyama_windows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_sim3_ransac_batch_rows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_sim3_ransac_mt_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_mt19937_seed_batch_dev": (C.c_int, [_vp, _vp, _i64, _vp]),

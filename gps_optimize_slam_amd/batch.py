@@ -295,8 +295,8 @@ def sim3_ransac_batch(src, dst, offsets, sample_idx, residual_threshold, min_inl
     R, t, s = torch.empty((B, 9), **f), torch.empty((B, 3), **f), torch.empty((B,), **f)
     st, nin = torch.empty((B,), dtype=torch.int32, device=src.device), torch.empty((B,), dtype=torch.int32, device=src.device)
     mask = torch.empty((src.shape[0],), dtype=torch.uint8, device=src.device)
-    check(_lib.load().gsf_sim3_ransac_batch_dev(context().handle, _p(src), _p(dst), _p(offsets), B, _p(sample_idx), trials, ms,
-                                                float(residual_threshold), int(min_inliers_needed), _p(R), _p(t), _p(s), _p(st), _p(mask), _p(nin)))
+    check(_lib.load().gsf_sim3_ransac_batch_rows_dev(context().handle, _p(src), _p(dst), _p(offsets), int(src.shape[0]), B, _p(sample_idx), trials, ms,
+                                                     float(residual_threshold), int(min_inliers_needed), _p(R), _p(t), _p(s), _p(st), _p(mask), _p(nin)))
     return R, t, s, st, mask, nin
 
 

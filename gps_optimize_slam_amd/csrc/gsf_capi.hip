@@ -52,6 +52,19 @@ int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes)
     return GSF_OK;
 }
 
+int ensure_k2b_scratch(gsf_ctx* ctx, size_t bytes)
+{
+    if (ctx->k2b_scratch_bytes >= bytes) return GSF_OK;
+    if (ctx->k2b_scratch) {
+        GSF_HIP(hipStreamSynchronize(ctx->stream));
+        GSF_HIP(hipFree(ctx->k2b_scratch));
+        ctx->k2b_scratch = nullptr; ctx->k2b_scratch_bytes = 0;
+    }
+    GSF_HIP(hipMalloc(&ctx->k2b_scratch, bytes + bytes / 4));
+    ctx->k2b_scratch_bytes = bytes + bytes / 4;
+    return GSF_OK;
+}
+
 static int ensure_arena(void** p, size_t* have, size_t bytes, bool pinned, hipStream_t stream)
 {
     if (*have >= bytes) return GSF_OK;
@@ -176,7 +189,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
-    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr;
+    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr; c->k2b_screen = 1; c->k2b_scratch = nullptr; c->k2b_scratch_bytes = 0;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
     // kernel-choice override for A/B runs of the whole test suite (the same meaning as gsf_set_option "block_kernel")
     if (const char* e = getenv("GSF_BLOCK_KERNEL")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->block_kernel = v; }
@@ -203,6 +216,7 @@ void gsf_destroy(gsf_ctx* ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->rng_scratch) (void)hipFree(ctx->rng_scratch);
     if (ctx->small_scratch) (void)hipFree(ctx->small_scratch);
+    if (ctx->k2b_scratch) (void)hipFree(ctx->k2b_scratch);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipEventDestroy(ctx->ev0);
@@ -229,6 +243,10 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     if (strcmp(key, "block_kernel") == 0) {
         if (value < -1 || value > 1) { set_error("gsf_set_option: block_kernel must be -1 (automatic), 0 (never) or 1 (whenever it applies)"); return GSF_ERR_INVALID_ARG; }
         ctx->block_kernel = (int)value; return GSF_OK;
+    }
+    if (strcmp(key, "k2b_screen") == 0) {
+        if (value < 0 || value > 1) { set_error("gsf_set_option: k2b_screen must be 1 (single-precision screen + exact re-check, default) or 0 (double throughout)"); return GSF_ERR_INVALID_ARG; }
+        ctx->k2b_screen = (int)value; return GSF_OK;
     }
     if (strcmp(key, "tape_draws") == 0) {
         if (value < -1 || value > 2 || value == 1) { set_error("gsf_set_option: tape_draws must be -1 (automatic: a few streams are drawn chip-wide), 0 (always one wave per stream) or 2 (tests: a tape cut short, so that the one-wave kernel takes over)"); return GSF_ERR_INVALID_ARG; }
@@ -324,7 +342,7 @@ int gsf_sim3_ransac_batch(gsf_ctx* ctx, const double* src, const double* dst, co
     double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
     int32_t* dst_ = st.out(status, (size_t)B); int32_t* dni = st.out(n_inliers, (size_t)B);
     uint8_t* dmask = st.out(inlier_mask, (size_t)total);
-    ST_RUN(gsf_sim3_ransac_batch_dev(ctx, dsrc, ddst, doff, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni));
+    ST_RUN(gsf_sim3_ransac_batch_rows_dev(ctx, dsrc, ddst, doff, total, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni));
 }
 
 // compute_sim3_transform_robust with the draws made on the device: mt_state[B][625] (host, in/out) is NumPy's legacy generator state
@@ -360,7 +378,7 @@ int gsf_sim3_ransac_mt_batch(gsf_ctx* ctx, const double* src, const double* dst,
     if (rc) return rc;
     GSF_HIP(hipMemcpyAsync(dstate, dst_in, (size_t)B * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     if (trials > 0 && (rc = launch_mt_choice(ctx, dstate, dcnt, B, trials, min_samples, didx, n_max))) return rc;
-    if ((rc = launch_sim3_ransac(ctx, dsrc, ddst, doff, nullptr, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni))) return rc;
+    if ((rc = launch_sim3_ransac(ctx, dsrc, ddst, doff, nullptr, B, didx, trials, min_samples, thr, min_inliers, dR, dt, ds, dst_, dmask, dni, total))) return rc;
     return st.finish();
 }
 

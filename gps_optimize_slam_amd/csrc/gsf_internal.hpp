@@ -23,8 +23,11 @@ struct gsf_ctx {
     // tape, transition tables and swap partners of the chip-wide draws (gsf_rng_tape.hip); separate from `scratch`, whose layout the caller of
     // launch_mt_choice may hold pointers into
     void* small_scratch;   // 512 B: arg-max keys of the split K2b launch (gsf_sim3.hip: up to 32 sets x 16 B)
+    void* k2b_scratch;     // K2b's rows as floats (screened residual counts, gsf_sim3.hip), grow-only
+    size_t k2b_scratch_bytes;
     void* rng_scratch;
     size_t rng_scratch_bytes;
+    int k2b_screen;        // K2b residual counts screened in packed single precision, exact re-check in the band (gsf_set_option "k2b_screen"): 1 default, 0 all double
     int tape_draws;        // chip-wide draws for a few streams (gsf_set_option "tape_draws"): -1 automatic, 0 never, 2 tests (tape cut short)
     int ekf_variant;       // reserved tuning knob (gsf_set_option "ekf_variant"); 0 = default
     int synth_variant;     // synthetic workload (gsf_set_option "synth_variant"): 0 = white SLAM noise (default), 1 = SURVEY 8d's random-walk drift
@@ -62,6 +65,7 @@ struct Idx {
 
 int ensure_scratch(gsf_ctx* ctx, size_t bytes);
 int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes);
+int ensure_k2b_scratch(gsf_ctx* ctx, size_t bytes);
 
 // wave-per-trajectory K4 / fused pipeline for the trajectory-major layout (gsf_ekf_wave.hip)
 int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
@@ -78,7 +82,8 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
 // K2b launch with optional per-set row counts (sets in fixed-stride slots: rows offsets[b] .. offsets[b] + counts[b])
 int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,
                        const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
-                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers);
+                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers,
+                       int64_t total_rows = 0 /* rows of src / dst if the host knows them: enables the single-precision screen */);
 // sample sets of the reference's RNG call, generated on the device (gsf_rng.hip): permutation(n_b)[:k] per trial from each set's
 // legacy MT19937 state; n_b = counts[b] (int32) -- asynchronous on the context's stream
 int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx,

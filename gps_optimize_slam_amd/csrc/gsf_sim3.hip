@@ -502,6 +502,122 @@ __device__ __forceinline__ unsigned long long ransac_scan_trials(const double* _
     }
     return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
 }
+// ---- the same count with the residuals SCREENED in packed single precision.  ransac_rows_kernel writes every set's rows once as floats
+// relative to the set's first row (x' = x - x0 and y' = y - y0, differences taken in double; six component arrays in the context's
+// workspace, read back through the SCALAR cache like the double rows -- a lane is a hypothesis, so a row is wave-uniform; the same
+// floats in LDS cost more than they saved: a 64-lane read of ONE 8- or 16-byte LDS word is serialised), a hypothesis becomes M = sR and
+// t' = M x0 + t - y0, and d = M x' + t' - y' is evaluated two rows per v_pk_fma_f32.  Every term of d carries a relative error of a few
+// 2^-24, bounded per hypothesis by e = 2^-24 * 8 * (|M|_rowsum * L_src + |t'|_max + L_dst) + 1e-6 m (L = largest |x'|, |y'| of the set),
+// so | |d|_f32 - |d| | <= sqrt(3) e:  a row is an inlier for certain below (thr - sqrt(3) e)^2 and an outlier for certain above
+// (thr + sqrt(3) e)^2; in between -- a few millimetres around a 4 m threshold, or a NaN -- the decision is taken in double by the code
+// above.  The count, hence the arg-max and everything after it, is the double-precision kernel's.
+typedef float rfloat2 __attribute__((ext_vector_type(2)));
+typedef float rfloat4 __attribute__((ext_vector_type(4)));
+struct RansacRows { const float* x[3]; const float* y[3]; double x0[3], y0[3]; double Lsrc, Ldst; };   // x / y: component arrays at the set's first row
+
+__device__ __forceinline__ unsigned long long ransac_scan_trials_screened(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0,
+                                                                          int64_t n, const RansacRows& rows, const int32_t* __restrict__ my_idx,
+                                                                          int first, int last, int step, int ms, double thr, bool& bad_index)
+{
+    long long best_cnt = -1; int best_trial = 0x7fffffff;
+    const int nn = (int)n;
+    for (int tr = first; tr < last; tr += step) {
+        double R[9], t[3], s;
+        bool in_range = true;
+        for (int k = 0; k < ms; ++k) { const int32_t ix = my_idx[(size_t)tr * ms + k]; in_range = in_range && ix >= 0 && (int64_t)ix < n; }
+        if (!in_range) { bad_index = true; continue; }
+        if (fit_sample(src, dst, i0, my_idx + (size_t)tr * ms, ms, R, t, s) == SIM3_NONE) continue;   // :408
+        double M[9], tp[3], rowsum = 0.0, tmax = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            M[c * 3] = s * R[c * 3]; M[c * 3 + 1] = s * R[c * 3 + 1]; M[c * 3 + 2] = s * R[c * 3 + 2];
+            tp[c] = M[c * 3] * rows.x0[0] + M[c * 3 + 1] * rows.x0[1] + M[c * 3 + 2] * rows.x0[2] + t[c] - rows.y0[c];
+            rowsum = fmax(rowsum, fabs(M[c * 3]) + fabs(M[c * 3 + 1]) + fabs(M[c * 3 + 2]));
+            tmax = fmax(tmax, fabs(tp[c]));
+        }
+        const double e3 = 1.7320508075688772 * (4.76837158203125e-07 * (rowsum * rows.Lsrc + tmax + rows.Ldst) + 1e-6);   // sqrt(3) * e, 8 * 2^-24
+        const double lo_d = thr - e3 > 0.0 ? (thr - e3) * (thr - e3) * (1.0 - 1e-6) : 0.0, hi_d = (thr + e3) * (thr + e3) * (1.0 + 1e-6);
+        // a band that cannot be trusted (NaN / inf model, thr <= 0, overflow in float): lo = 0 and hi = inf send every row to the double path
+        const bool usable = thr > 0.0 && hi_d < 1e30 && e3 == e3;
+        const float lo = usable ? (float)lo_d * (1.0f - 2e-7f) : 0.0f, hi = usable ? (float)hi_d * (1.0f + 2e-7f) : INFINITY;
+        const float m00 = (float)M[0], m01 = (float)M[1], m02 = (float)M[2], m10 = (float)M[3], m11 = (float)M[4], m12 = (float)M[5],
+                    m20 = (float)M[6], m21 = (float)M[7], m22 = (float)M[8], t0 = (float)tp[0], t1 = (float)tp[1], t2 = (float)tp[2];
+        long long cnt = 0;
+        int r = 0;
+        // eight rows per round: four packed pairs, ONE test whether any of the eight fell into the band -- then, and only for the lanes
+        // it happened to, the eight are counted again in double
+        for (; r + 8 <= nn; r += 8) {
+            int cg = 0; bool unc = false;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const rfloat2 X = { rows.x[0][r + u], rows.x[0][r + u + 1] }, Y = { rows.x[1][r + u], rows.x[1][r + u + 1] }, Z = { rows.x[2][r + u], rows.x[2][r + u + 1] };
+                const rfloat2 A = { rows.y[0][r + u], rows.y[0][r + u + 1] }, Bv = { rows.y[1][r + u], rows.y[1][r + u + 1] }, C = { rows.y[2][r + u], rows.y[2][r + u + 1] };
+                const rfloat2 dx = __builtin_elementwise_fma(Z, (rfloat2)m02, __builtin_elementwise_fma(Y, (rfloat2)m01, __builtin_elementwise_fma(X, (rfloat2)m00, (rfloat2)t0))) - A;
+                const rfloat2 dy = __builtin_elementwise_fma(Z, (rfloat2)m12, __builtin_elementwise_fma(Y, (rfloat2)m11, __builtin_elementwise_fma(X, (rfloat2)m10, (rfloat2)t1))) - Bv;
+                const rfloat2 dz = __builtin_elementwise_fma(Z, (rfloat2)m22, __builtin_elementwise_fma(Y, (rfloat2)m21, __builtin_elementwise_fma(X, (rfloat2)m20, (rfloat2)t2))) - C;
+                const rfloat2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const bool in0 = d2.x < lo, in1 = d2.y < lo;
+                cg += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+                unc = unc || !(in0 || d2.x > hi) || !(in1 || d2.y > hi);           // inside the band, or NaN
+            }
+            if (unc) {                                                     // rare
+                cg = 0;
+                for (int u = 0; u < 8; ++u) cg += is_inlier(src, dst, i0 + r + u, R, t, s, thr) ? 1 : 0;
+            }
+            cnt += cg;
+        }
+        for (; r < nn; ++r) cnt += is_inlier(src, dst, i0 + r, R, t, s, thr) ? 1 : 0;
+        if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
+    }
+    return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+}
+// rows of every set as floats relative to the set's first row: frows = six arrays of `total` floats (x', y', z' of src, then of dst),
+// fhdr[b] = { x0[3], y0[3], L_src, L_dst } (doubles)
+__global__ __launch_bounds__(256) void ransac_rows_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ counts, int64_t total, float* __restrict__ frows,
+                                                          double* __restrict__ fhdr)
+{
+    __shared__ double sh_max[8];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
+    if (n <= 0 || i0 < 0 || i0 + n > total) { if (tid == 0) fhdr[b * 8 + 6] = NAN; return; }        // NaN extent: the set is counted in double
+    double x0[3], y0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x0[c] = src[i0 * 3 + c]; y0[c] = dst[i0 * 3 + c]; }
+    double ls = 0.0, ld = 0.0;
+    for (int64_t i = tid; i < n; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double a = src[(i0 + i) * 3 + c] - x0[c], bb = dst[(i0 + i) * 3 + c] - y0[c];
+            frows[(int64_t)c * total + i0 + i] = (float)a; frows[(int64_t)(3 + c) * total + i0 + i] = (float)bb;
+            ls = fmax(ls, fabs(a)); ld = fmax(ld, fabs(bb));                // fmax drops NaN: a NaN row goes to the double path on its own
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ls = fmax(ls, __shfl_xor(ls, o, 64)); ld = fmax(ld, __shfl_xor(ld, o, 64)); }
+    if ((tid & 63) == 0) { sh_max[(tid >> 6) * 2] = ls; sh_max[(tid >> 6) * 2 + 1] = ld; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { ls = fmax(ls, sh_max[w * 2]); ld = fmax(ld, sh_max[w * 2 + 1]); }
+        ls = fmax(ls, sh_max[0]); ld = fmax(ld, sh_max[1]);
+        for (int c = 0; c < 3; ++c) { fhdr[b * 8 + c] = x0[c]; fhdr[b * 8 + 3 + c] = y0[c]; }
+        fhdr[b * 8 + 6] = ls; fhdr[b * 8 + 7] = ld;
+    }
+}
+__device__ __forceinline__ bool ransac_rows_of_set(const float* __restrict__ frows, const double* __restrict__ fhdr, int64_t total, int64_t b, int64_t i0,
+                                                   RansacRows& rows)
+{
+    if (!frows) return false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rows.x[c] = frows + (int64_t)c * total + i0; rows.y[c] = frows + (int64_t)(3 + c) * total + i0;
+        rows.x0[c] = fhdr[b * 8 + c]; rows.y0[c] = fhdr[b * 8 + 3 + c];
+    }
+    rows.Lsrc = fhdr[b * 8 + 6]; rows.Ldst = fhdr[b * 8 + 7];
+    return rows.Lsrc == rows.Lsrc;                                           // NaN: not staged
+}
+
 __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long key)
 {
 #pragma unroll
@@ -594,7 +710,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
     double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
-    int32_t* __restrict__ n_inliers)
+    int32_t* __restrict__ n_inliers, const float* __restrict__ frows, const double* __restrict__ fhdr, int64_t total)
 {
     __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
     __shared__ double sh_fit[13];
@@ -610,7 +726,13 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     }
     const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
     bool bad_index = false;
-    unsigned long long key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+    unsigned long long key;
+    RansacRows rows;
+    if (ransac_rows_of_set(frows, fhdr, total, b, i0, rows)) {               // block-uniform
+        key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+    } else {
+        key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+    }
     const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
     if ((tid & 63) == 0) sh_key[tid >> 6] = key;
     __syncthreads();
@@ -625,15 +747,22 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
 // ransac_batch_kernel does.  One set x 1 000 trials: 130 us on one CU -> two launches of ~25 and ~8 us.
 __global__ __launch_bounds__(64) void ransac_scan_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
                                                          const int32_t* __restrict__ counts, const int32_t* __restrict__ sample_idx, int trials, int ms,
-                                                         double thr, unsigned long long* __restrict__ keys)
+                                                         double thr, unsigned long long* __restrict__ keys, const float* __restrict__ frows,
+                                                         const double* __restrict__ fhdr, int64_t total)
 {
     const int64_t b = blockIdx.y;
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
     if (n < ms) return;
     const int tr = blockIdx.x * 64 + threadIdx.x;
     bool bad_index = false;
-    const unsigned long long key = wave_max_key(ransac_scan_trials(src, dst, i0, n, sample_idx + (size_t)b * (size_t)trials * (size_t)ms, tr,
-                                                                   tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
+    const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
+    unsigned long long key;
+    RansacRows rows;
+    if (ransac_rows_of_set(frows, fhdr, total, b, i0, rows)) {
+        key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, tr, tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
+    } else {
+        key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tr, tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
+    }
     const bool any_bad = __ballot(bad_index) != 0ull;
     if (threadIdx.x == 0) {
         if (key) atomicMax(&keys[b * 2], key);
@@ -694,21 +823,33 @@ __global__ __launch_bounds__(256) void apply_sim3_kernel(const double* __restric
 namespace gsf {
 int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,
                        const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
-                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
+                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers, int64_t total_rows)
 {
+    // residual counts screened in packed single precision with an exact double re-check inside the error band (the counts are the
+    // double kernel's); needs the rows as floats in the workspace, hence their total number (0 = unknown to the host: double
+    // throughout, as with gsf_set_option "k2b_screen" 0)
+    const float* frows = nullptr; const double* fhdr = nullptr;
+    if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows <= ((int64_t)1 << 31) && trials >= 64) {
+        const size_t hdr_bytes = ((size_t)B * 64 + 255) & ~(size_t)255;
+        const int rc = ensure_k2b_scratch(ctx, hdr_bytes + (size_t)total_rows * 24);
+        if (rc) return rc;
+        double* h = (double*)ctx->k2b_scratch; float* f = (float*)((char*)ctx->k2b_scratch + hdr_bytes);
+        hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, h);
+        frows = f; fhdr = h;
+    }
     if (B <= RANSAC_SPLIT_MAX_SETS && trials >= 256) {
         // few sets: hypotheses spread over the chip, then one finishing block per set
         unsigned long long* keys = (unsigned long long*)ctx->small_scratch;
         GSF_HIP(hipMemsetAsync(keys, 0, (size_t)B * 16, ctx->stream));
         hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
-                           sample_idx, (int)trials, (int)min_samples, thr, keys);
+                           sample_idx, (int)trials, (int)min_samples, thr, keys, frows, fhdr, total_rows);
         hipLaunchKernelGGL(ransac_finish_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
                            (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
     }
     hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
-                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers);
+                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers, frows, fhdr, total_rows);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -780,6 +921,21 @@ int gsf_sim3_ransac_batch_dev(gsf_ctx* ctx, const double* src, const double* dst
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
     return launch_sim3_ransac(ctx, src, dst, offsets, nullptr, B, sample_idx, trials, min_samples, thr, min_inliers, R, t, s, status, inlier_mask, n_inliers);
+}
+
+int gsf_sim3_ransac_batch_rows_dev(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, int64_t total_rows, int64_t B,
+                                   const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers,
+                                   double* R, double* t, double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers)
+{
+    GSF_REQUIRE(ctx && offsets && R && t && s && status && inlier_mask && n_inliers, "NULL argument");
+    GSF_REQUIRE(B >= 0 && trials >= 0 && total_rows >= 0, "negative B, trials or total_rows");
+    GSF_REQUIRE(min_samples >= 1 && min_samples <= RANSAC_MAX_SAMPLES, "min_samples must be in [1,4096]");
+    GSF_REQUIRE(trials == 0 || sample_idx, "sample_idx is NULL");
+    GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
+    if (B == 0) return GSF_OK;
+    GSF_HIP(hipSetDevice(ctx->device));
+    return launch_sim3_ransac(ctx, src, dst, offsets, nullptr, B, sample_idx, trials, min_samples, thr, min_inliers, R, t, s, status, inlier_mask, n_inliers,
+                              total_rows);
 }
 
 int gsf_apply_sim3_batch_dev(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R,

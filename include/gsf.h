@@ -102,6 +102,8 @@ GSF_API int gsf_synchronize(gsf_ctx *ctx);
      "block_kernel"   -1 / 0 never (what -1 means today) / 1 whenever it applies: workgroup-per-trajectory EKF kernel for 64 < N <= 1024
      "tape_draws"     -1 automatic (default): up to 16 MT19937 streams of <= 2040 rows are drawn chip-wide (csrc/gsf_rng_tape.hip) /
                       0 always one wave per stream / 2 tests only (a tape cut short: the one-wave kernel must take over)
+     "k2b_screen"     1 (default): the residual counts of the RANSAC hypotheses are screened in packed single precision and re-checked in
+                      double inside the rounding band (identical counts) / 0: double throughout
      "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift
      "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
@@ -206,6 +208,14 @@ GSF_API int gsf_sim3_ransac_batch_dev(gsf_ctx *ctx, const double *src, const dou
                               const int32_t *sample_idx, int32_t trials, int32_t min_samples, double residual_threshold,
                               int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,
                               uint8_t *inlier_mask, int32_t *n_inliers);
+/* the same with the number of rows of src / dst (= offsets[B]) known to the HOST: the library can then keep the rows a second time
+   as floats in its workspace and SCREEN the residual counts of the hypotheses in packed single precision, re-checking in double
+   every row inside the rounding band -- the counts, masks and fits are those of the double count, in ~0.6 of the time
+   (gsf_set_option "k2b_screen" 0 switches the screen off).  The host-pointer forms use it by themselves. */
+GSF_API int gsf_sim3_ransac_batch_rows_dev(gsf_ctx *ctx, const double *src, const double *dst, const int64_t *offsets, int64_t total_rows,
+                                           int64_t B, const int32_t *sample_idx, int32_t trials, int32_t min_samples,
+                                           double residual_threshold, int32_t min_inliers_needed, double *R, double *t, double *s,
+                                           int32_t *status, uint8_t *inlier_mask, int32_t *n_inliers);
 GSF_API int gsf_sim3_ransac_batch(gsf_ctx *ctx, const double *src, const double *dst, const int64_t *offsets, int64_t B,
                           const int32_t *sample_idx, int32_t trials, int32_t min_samples, double residual_threshold,
                           int32_t min_inliers_needed, double *R, double *t, double *s, int32_t *status,

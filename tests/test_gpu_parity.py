@@ -1229,6 +1229,49 @@ def test_device_mt19937_choice_matches_numpy(B):
     assert np.random.random() == after
 
 
+def test_k2b_single_precision_screen_keeps_the_double_counts(B):
+    """K2b counts the inliers of every hypothesis with a packed single-precision screen and re-checks in double every row inside the
+    rounding band (csrc/gsf_sim3.hip): counts, masks, fits and statuses must be those of the all-double count -- also with rows planted
+    from nanometres to centimetres off the threshold sphere, a threshold inside the noise, one tiny enough that the band swallows it,
+    a NaN row, a wild row 5 000 km away (which blows the set's error bound up and sends everything to the double path), and for one
+    set (hypotheses spread over single-wave blocks) as well as many."""
+    import torch
+    rng = np.random.default_rng(12)
+
+    def run(nt, npts, trials, thr, band_rows, wild=False):
+        bt = B.TrajectoryBatch.synthetic(nt, npts, layout=0, seed=5)
+        src = bt.pos.reshape(nt * npts, 3).contiguous()
+        g3 = bt.gps.reshape(nt * npts, 3)
+        dst = torch.where(torch.isnan(g3), src + torch.nanmean(g3 - src, dim=0, keepdim=True), g3).contiguous()
+        d = dst.reshape(nt, npts, 3)
+        for b_ in range(nt):
+            rows = rng.choice(npts, size=band_rows, replace=False)
+            u = rng.normal(size=(band_rows, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+            d[b_, rows] += torch.as_tensor(u * (thr + rng.normal(size=(band_rows, 1)) * 10.0 ** rng.uniform(-9, -2, size=(band_rows, 1))), device="cuda")
+        if wild:
+            d[0, 7] = 0.0; d[min(1, nt - 1), 9, 1] = float("nan")
+        offs = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device="cuda")
+        idx = torch.as_tensor(np.stack([np.stack([rng.permutation(npts)[:4] for _ in range(trials)]) for _ in range(nt)]).astype(np.int32)).cuda()
+        res = {}
+        for scr in (1, 0):
+            B.context().set_option("k2b_screen", scr)
+            res[scr] = [o.cpu().numpy() for o in B.sim3_ransac_batch(src, dst, offs, idx, thr, 4)]
+        for a, b_ in zip(res[1], res[0]):
+            np.testing.assert_array_equal(a, b_)
+        return res[1]
+
+    try:
+        out = run(48, 271, 300, 4.0, 40)
+        assert (out[5] > 150).all()                                      # n_inliers: the fits found the tracks
+        run(48, 271, 300, 0.05, 0)
+        run(48, 271, 300, 1e-4, 0)
+        run(40, 271, 300, 4.0, 20, wild=True)
+        run(1, 271, 1000, 4.0, 40)
+        run(3, 1000, 400, 4.0, 100)
+    finally:
+        B.context().set_option("k2b_screen", 1)
+
+
 def test_chip_wide_draws_match_numpy(B):
     """The chip-wide route of the draws (csrc/gsf_rng_tape.hip: tape -> transition tables -> composed walk -> replay -> trace) against
     NumPy: sample sets trial by trial and the generator state afterwards, for populations from 2 to 2040, k up to 64, entries at
