@@ -32,11 +32,16 @@ ROWS = [
     ("aux", "ransac_batch_kernel", 256000, "K2b 1 000 x (271 points, 1 000 fed trials)", 1000, None, "trajectories"),
     ("aux", "mt_choice_kernel", 64000, "device draws: 1 000 streams x 1 000 trials of permutation(271)[:4]", 1_000_000, None, "trials"),
     ("bench_default", "mt_tape_kernel", 512, "device draws, ONE stream x 1 000 trials (C1 drop-in), chip-wide route: the tape", 1000, None, "trials"),
-    ("bench_default", "mt_transition_kernel", 240000, "... transition tables of 750 segments x 270 start states", 1000, None, "trials"),
-    ("bench_default", "mt_resolve_kernel", 48000, "... replay of the segments", 1000, None, "trials"),
+    ("bench_default", "mt_transition_kernel", 47744, "... transition tables of 746 segments x 270 start states", 1000, None, "trials"),
+    ("bench_default", "mt_compose_kernel", 6912, "... composed tables (27 groups of 28 segments)", 1000, None, "trials"),
+    ("bench_default", "mt_expand_kernel", 256, "... walk of the 27 composed tables", 1000, None, "trials"),
+    ("bench_default", "mt_expand_kernel", 6912, "... starts handed down to the segments", 1000, None, "trials"),
+    ("bench_default", "mt_resolve_kernel", 47744, "... replay of the segments", 1000, None, "trials"),
     ("bench_default", "mt_tape_trace_kernel", 4032, "... trace of the four sample positions", 1000, None, "trials"),
     ("bench_default", "gps_prefilter_chain_kernel", 64, "GPS pre-filter chain of ONE log (279 fixes, 12 window-axis problems)", 279, None, "fixes"),
     ("bench_default", "ransac_scan_kernel", 1024, "K2b for ONE set: 1 000 hypotheses over 16 single-wave blocks", 1000, None, "hypotheses"),
+    ("bench_default", "ransac_finish_kernel", 256, "... winner's mask and final fit", 1000, None, "hypotheses"),
+    ("bench_default", "ransac_batch_kernel", 256000, "K2b inside the robust chain 1 000 x 271 (valid rows compacted, 1 000 drawn trials)", 1000, None, "trajectories"),
     ("bench_default", "eval_errors_lds_kernel", 256, "error metric of ONE 271-pose track", 271, None, "poses"),
     ("aux", "time_align_kernel", 64000, "time alignment 1 000 x (271 stamps, 279 fixes)", 271_000, None, "stamps"),
     ("aux", "ransac_poly_kernel<128>", 3840000, "GPS pre-filter problems: 30 000 x (150 rows, 50 trials of 6)", 30000, None, "problems"),
