@@ -238,6 +238,24 @@ def profiled_issue(workload, kernel, grid_threads, kernel_ms):
         return None
 
 
+def profiled_stream_rate():
+    """Bytes per second the memory system moved for K3 (apply_sim3_kernel: the same 24 / 32-byte-stride pose rows read and written, no
+    arithmetic to speak of) in the committed profile of the auxiliary kernels: the practical ceiling of this access pattern under a mixed
+    read + write stream (the C3 timing probes).  None when the profile is not there."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_aux_by_kernel_and_grid.csv")))
+    if not files:
+        return None
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            if r["kernel"] == "apply_sim3_kernel" and int(r["grid_threads"]) == 25600000:       # 1e8 poses, 112 B each
+                return 1e8 * 112 / (float(r["avg_us"]) * 1e-6), os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # C5-shaped leg: fuse a big per-GPU shard chunk by chunk, all-gather every chunk's poses while the next chunk is fused
 # ----------------------------------------------------------------------------------------------------------------------
@@ -609,6 +627,20 @@ def worker(args):
             result["roofline"]["bound"] = "valu"
             result["roofline"]["bound_note"] = ("counters: the launch's VALU wave-instructions at one per 4 cycles on all 1 024 SIMDs take a larger share of the "
                                                 "kernel time than its algorithmic bytes at 8 TB/s; achieved / peak / frac stay the HBM figures")
+    # many waves per SIMD (C3-sized batches): the counter traffic at the rate K3 reaches with the same rows is the first wall there -- the
+    # timing probes of DESIGN.md section 5 (either stream alone hides behind the arithmetic, both together do not)
+    stream = profiled_stream_rate()
+    if stream is not None and traffic and Bn >= 2 * SIMDS:
+        floor_ms = traffic / stream[0] * 1e3
+        result["roofline"]["stream"] = {"counter_bytes_per_launch": traffic, "rate_of_K3_same_rows_GBps": stream[0] / 1e9, "floor_ms": floor_ms,
+                                        "frac": floor_ms / kern_ms, "source": stream[1]}
+        if floor_ms / kern_ms > 1.0:
+            result["roofline"]["stream"]["note"] = ("above 1: part of this launch's counted traffic (the fit pass's second read) is served by the Infinity Cache, "
+                                                    "which K3's streaming rate does not describe")
+        elif floor_ms / kern_ms > max(result["roofline"]["frac"], (valu or {}).get("frac", 0.0)):
+            result["roofline"]["bound"] = "hbm"
+            result["roofline"]["bound_note"] = ("the bytes the counters saw, at the rate apply_sim3_kernel moves the same 24 / 32-byte-stride rows (mixed read + write), "
+                                                "take a larger share of the kernel time than the VALU issue floor; achieved / peak / frac stay the algorithmic bytes at 8 TB/s")
     if args.kernel == "pipeline":
         torch.cuda.synchronize()
         # how many tracks of the timed batch took the Jacobi-SVD fallback of the fit (status bit GSF_SIM3_FLAG_SVD_FALLBACK << 8): one such
