@@ -507,20 +507,22 @@ __device__ __forceinline__ unsigned long long ransac_scan_trials(const double* _
 // workspace, read back through the SCALAR cache like the double rows -- a lane is a hypothesis, so a row is wave-uniform; the same
 // floats in LDS cost more than they saved: a 64-lane read of ONE 8- or 16-byte LDS word is serialised), a hypothesis becomes M = sR and
 // t' = M x0 + t - y0, and d = M x' + t' - y' is evaluated two rows per v_pk_fma_f32.  Every term of d carries a relative error of a few
-// 2^-24, bounded per hypothesis by e = 2^-24 * 8 * (|M|_rowsum * L_src + |t'|_max + L_dst) + 1e-6 m (L = largest |x'|, |y'| of the set),
+// 2^-24, bounded per hypothesis by e = 2^-24 * 8 * (|M|_rowsum * L_src + |t'|_max + L_dst) + 1e-6 m (L = largest |x'|, |y'| of the set's
+// NEAR rows; rows farther than 65 km from the reference point, or not finite, are set apart by ransac_rows_kernel and screened with a
+// band of their own -- wide, but a fix 5 000 km off is still an outlier for certain),
 // so | |d|_f32 - |d| | <= sqrt(3) e:  a row is an inlier for certain below (thr - sqrt(3) e)^2 and an outlier for certain above
 // (thr + sqrt(3) e)^2; in between -- a few millimetres around a 4 m threshold, or a NaN -- the decision is taken in double by the code
 // above.  The count, hence the arg-max and everything after it, is the double-precision kernel's.
 typedef float rfloat2 __attribute__((ext_vector_type(2)));
 typedef float rfloat4 __attribute__((ext_vector_type(4)));
-struct RansacRows { const float* x[3]; const float* y[3]; double x0[3], y0[3]; double Lsrc, Ldst; };   // x / y: component arrays at the set's first row
+struct RansacRows { const float* x[3]; const float* y[3]; const int32_t* ridx; double x0[3], y0[3]; double Lsrc, Ldst, Fsrc, Fdst; int n_near; };   // x / y / ridx: at the set's first slot
 
 __device__ __forceinline__ unsigned long long ransac_scan_trials_screened(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0,
                                                                           int64_t n, const RansacRows& rows, const int32_t* __restrict__ my_idx,
                                                                           int first, int last, int step, int ms, double thr, bool& bad_index)
 {
     long long best_cnt = -1; int best_trial = 0x7fffffff;
-    const int nn = (int)n;
+    const int nn = rows.n_near, nall = (int)n;                             // slots 0 .. nn-1: near rows (screened); nn .. nall-1: far rows (double)
     for (int tr = first; tr < last; tr += step) {
         double R[9], t[3], s;
         bool in_range = true;
@@ -535,86 +537,174 @@ __device__ __forceinline__ unsigned long long ransac_scan_trials_screened(const 
             rowsum = fmax(rowsum, fabs(M[c * 3]) + fabs(M[c * 3 + 1]) + fabs(M[c * 3 + 2]));
             tmax = fmax(tmax, fabs(tp[c]));
         }
-        const double e3 = 1.7320508075688772 * (4.76837158203125e-07 * (rowsum * rows.Lsrc + tmax + rows.Ldst) + 1e-6);   // sqrt(3) * e, 8 * 2^-24
-        const double lo_d = thr - e3 > 0.0 ? (thr - e3) * (thr - e3) * (1.0 - 1e-6) : 0.0, hi_d = (thr + e3) * (thr + e3) * (1.0 + 1e-6);
-        // a band that cannot be trusted (NaN / inf model, thr <= 0, overflow in float): lo = 0 and hi = inf send every row to the double path
-        const bool usable = thr > 0.0 && hi_d < 1e30 && e3 == e3;
-        const float lo = usable ? (float)lo_d * (1.0f - 2e-7f) : 0.0f, hi = usable ? (float)hi_d * (1.0f + 2e-7f) : INFINITY;
+        // band of a group of rows whose largest |x'| / |y'| are Ls / Ld: lo = 0 and hi = inf (every row to the double path) when it cannot be
+        // trusted -- NaN / inf model, thr <= 0, overflow in float
+        auto band = [&](const double Ls, const double Ld, float& lo, float& hi) {
+            const double e3 = 1.7320508075688772 * (4.76837158203125e-07 * (rowsum * Ls + tmax + Ld) + 1e-6);   // sqrt(3) * e, 8 * 2^-24
+            const double lo_d = thr - e3 > 0.0 ? (thr - e3) * (thr - e3) * (1.0 - 1e-6) : 0.0, hi_d = (thr + e3) * (thr + e3) * (1.0 + 1e-6);
+            const bool usable = thr > 0.0 && hi_d < 1e30 && e3 == e3;
+            lo = usable ? (float)lo_d * (1.0f - 2e-7f) : 0.0f; hi = usable ? (float)hi_d * (1.0f + 2e-7f) : INFINITY;
+        };
+        float lo_n, hi_n, lo_f, hi_f;
+        band(rows.Lsrc, rows.Ldst, lo_n, hi_n);
+        band(rows.Fsrc, rows.Fdst, lo_f, hi_f);
         const float m00 = (float)M[0], m01 = (float)M[1], m02 = (float)M[2], m10 = (float)M[3], m11 = (float)M[4], m12 = (float)M[5],
                     m20 = (float)M[6], m21 = (float)M[7], m22 = (float)M[8], t0 = (float)tp[0], t1 = (float)tp[1], t2 = (float)tp[2];
         long long cnt = 0;
-        int r = 0;
-        // eight rows per round: four packed pairs, ONE test whether any of the eight fell into the band -- then, and only for the lanes
-        // it happened to, the eight are counted again in double
-        for (; r + 8 <= nn; r += 8) {
-            int cg = 0; bool unc = false;
+        // slots r0 .. r1-1, eight rows per round: four packed pairs, ONE test whether any of the eight fell into the band -- then, and only
+        // for the lanes it happened to, the eight are counted again in double; the rows left over (< 8) always are
+        auto count_rows = [&](const int r0, const int r1, const float lo, const float hi) {
+            int r = r0;
+            for (; r + 8 <= r1; r += 8) {
+                int cg = 0; bool unc = false;
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                const rfloat2 X = { rows.x[0][r + u], rows.x[0][r + u + 1] }, Y = { rows.x[1][r + u], rows.x[1][r + u + 1] }, Z = { rows.x[2][r + u], rows.x[2][r + u + 1] };
-                const rfloat2 A = { rows.y[0][r + u], rows.y[0][r + u + 1] }, Bv = { rows.y[1][r + u], rows.y[1][r + u + 1] }, C = { rows.y[2][r + u], rows.y[2][r + u + 1] };
-                const rfloat2 dx = __builtin_elementwise_fma(Z, (rfloat2)m02, __builtin_elementwise_fma(Y, (rfloat2)m01, __builtin_elementwise_fma(X, (rfloat2)m00, (rfloat2)t0))) - A;
-                const rfloat2 dy = __builtin_elementwise_fma(Z, (rfloat2)m12, __builtin_elementwise_fma(Y, (rfloat2)m11, __builtin_elementwise_fma(X, (rfloat2)m10, (rfloat2)t1))) - Bv;
-                const rfloat2 dz = __builtin_elementwise_fma(Z, (rfloat2)m22, __builtin_elementwise_fma(Y, (rfloat2)m21, __builtin_elementwise_fma(X, (rfloat2)m20, (rfloat2)t2))) - C;
-                const rfloat2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                const bool in0 = d2.x < lo, in1 = d2.y < lo;
-                cg += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-                unc = unc || !(in0 || d2.x > hi) || !(in1 || d2.y > hi);           // inside the band, or NaN
+                for (int u = 0; u < 8; u += 2) {
+                    const rfloat2 X = { rows.x[0][r + u], rows.x[0][r + u + 1] }, Y = { rows.x[1][r + u], rows.x[1][r + u + 1] }, Z = { rows.x[2][r + u], rows.x[2][r + u + 1] };
+                    const rfloat2 A = { rows.y[0][r + u], rows.y[0][r + u + 1] }, Bv = { rows.y[1][r + u], rows.y[1][r + u + 1] }, C = { rows.y[2][r + u], rows.y[2][r + u + 1] };
+                    const rfloat2 dx = __builtin_elementwise_fma(Z, (rfloat2)m02, __builtin_elementwise_fma(Y, (rfloat2)m01, __builtin_elementwise_fma(X, (rfloat2)m00, (rfloat2)t0))) - A;
+                    const rfloat2 dy = __builtin_elementwise_fma(Z, (rfloat2)m12, __builtin_elementwise_fma(Y, (rfloat2)m11, __builtin_elementwise_fma(X, (rfloat2)m10, (rfloat2)t1))) - Bv;
+                    const rfloat2 dz = __builtin_elementwise_fma(Z, (rfloat2)m22, __builtin_elementwise_fma(Y, (rfloat2)m21, __builtin_elementwise_fma(X, (rfloat2)m20, (rfloat2)t2))) - C;
+                    const rfloat2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    const bool in0 = d2.x < lo, in1 = d2.y < lo;
+                    cg += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+                    unc = unc || !(in0 || d2.x > hi) || !(in1 || d2.y > hi);       // inside the band, or NaN
+                }
+                if (unc) {                                                 // rare
+                    cg = 0;
+                    for (int u = 0; u < 8; ++u) cg += is_inlier(src, dst, i0 + rows.ridx[r + u], R, t, s, thr) ? 1 : 0;
+                }
+                cnt += cg;
             }
-            if (unc) {                                                     // rare
-                cg = 0;
-                for (int u = 0; u < 8; ++u) cg += is_inlier(src, dst, i0 + r + u, R, t, s, thr) ? 1 : 0;
+            if (r < r1) {                                                  // eight row numbers, then their rows, in flight together
+                int id[8]; double d2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) id[u] = rows.ridx[r + u < r1 ? r + u : r1 - 1];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d2[u] = resid2(src, dst, i0 + id[u], R, t, s);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cnt += (r + u < r1 && within(d2[u], thr)) ? 1 : 0;
             }
-            cnt += cg;
-        }
-        for (; r < nn; ++r) cnt += is_inlier(src, dst, i0 + r, R, t, s, thr) ? 1 : 0;
+        };
+        count_rows(0, nn, lo_n, hi_n);                                     // near rows
+        count_rows(nn, nall, lo_f, hi_f);                                  // far rows: their own, much wider band -- a fix 5 000 km off is an outlier for certain
         if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
     }
     return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
 }
-// rows of every set as floats relative to the set's first row: frows = six arrays of `total` floats (x', y', z' of src, then of dst),
-// fhdr[b] = { x0[3], y0[3], L_src, L_dst } (doubles)
+// rows of every set as floats relative to the set's first row, NEAR rows first: frows = six arrays of `total` floats (x', y', z' of src,
+// then of dst), ridx = the row each slot came from (offset inside the set), fhdr[b] = { x0[3], y0[3], L_src, L_dst, n_near } (16 doubles
+// per set; [9], [10] = extents of the far rows).  A row is FAR when it lies more than RANSAC_NEAR_M from the reference point in any
+// coordinate, or holds a NaN / inf: far rows are listed after the near ones and screened against their own extent, so that one wild fix (a
+// zero row is 5 000 km from a UTM track) cannot inflate the rounding bound of the whole set -- L is taken over the near rows only.
+constexpr double RANSAC_NEAR_M = 65536.0;
+constexpr int RANSAC_HDR = 16;
 __global__ __launch_bounds__(256) void ransac_rows_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
                                                           const int32_t* __restrict__ counts, int64_t total, float* __restrict__ frows,
-                                                          double* __restrict__ fhdr)
+                                                          int32_t* __restrict__ ridx, double* __restrict__ fhdr)
 {
-    __shared__ double sh_max[8];
-    const int tid = threadIdx.x;
+    __shared__ double sh_max[16];
+    __shared__ int sh_cnt[4];
+    __shared__ int sh_near;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b = blockIdx.x;
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
-    if (n <= 0 || i0 < 0 || i0 + n > total) { if (tid == 0) fhdr[b * 8 + 6] = NAN; return; }        // NaN extent: the set is counted in double
+    if (n <= 0 || i0 < 0 || i0 + n > total) { if (tid == 0) fhdr[b * RANSAC_HDR + 6] = NAN; return; }   // NaN extent: the set is counted in double
+    // reference point: the component-wise median of five probe rows (first, quartiles, last) -- one or two wild rows among them (a set
+    // that STARTS with a missing fix is ordinary) do not drag it away from the track.  It need not be a row; NaN sorts last.
     double x0[3], y0[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { x0[c] = src[i0 * 3 + c]; y0[c] = dst[i0 * 3 + c]; }
-    double ls = 0.0, ld = 0.0;
-    for (int64_t i = tid; i < n; i += 256) {
+    {
+        const int64_t pr[5] = { 0, n / 4, n / 2, (3 * n) / 4, n - 1 };
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double a = src[(i0 + i) * 3 + c] - x0[c], bb = dst[(i0 + i) * 3 + c] - y0[c];
-            frows[(int64_t)c * total + i0 + i] = (float)a; frows[(int64_t)(3 + c) * total + i0 + i] = (float)bb;
-            ls = fmax(ls, fabs(a)); ld = fmax(ld, fabs(bb));                // fmax drops NaN: a NaN row goes to the double path on its own
+            double va[5], vb[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { va[k] = src[(i0 + pr[k]) * 3 + c]; vb[k] = dst[(i0 + pr[k]) * 3 + c]; }
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2)
+#pragma unroll
+                for (int k = 0; k + 1 < 5 - p2; ++k) {
+                    if (!(va[k] <= va[k + 1])) { const double tt = va[k]; va[k] = va[k + 1]; va[k + 1] = tt; }     // NaN bubbles to the end
+                    if (!(vb[k] <= vb[k + 1])) { const double tt = vb[k]; vb[k] = vb[k + 1]; vb[k + 1] = tt; }
+                }
+            x0[c] = va[2]; y0[c] = vb[2];
         }
     }
+    auto row = [&](int64_t i, double* a, double* bb) {
+        double g = 0.0; bool fin = true;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ls = fmax(ls, __shfl_xor(ls, o, 64)); ld = fmax(ld, __shfl_xor(ld, o, 64)); }
-    if ((tid & 63) == 0) { sh_max[(tid >> 6) * 2] = ls; sh_max[(tid >> 6) * 2 + 1] = ld; }
+        for (int c = 0; c < 3; ++c) {
+            a[c] = src[(i0 + i) * 3 + c] - x0[c]; bb[c] = dst[(i0 + i) * 3 + c] - y0[c];
+            fin = fin && fabs(a[c]) <= RANSAC_NEAR_M && fabs(bb[c]) <= RANSAC_NEAR_M;       // false for NaN / inf as well
+            g = fmax(g, fmax(fabs(a[c]), fabs(bb[c])));
+        }
+        return fin;
+    };
+    // pass 1: how many near rows
+    int mine = 0;
+    for (int64_t i = tid; i < n; i += 256) { double a[3], bb[3]; mine += row(i, a, bb) ? 1 : 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) sh_cnt[wave] = mine;
+    __syncthreads();
+    const int n_near = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+    __syncthreads();
+    // pass 2: near rows to slots 0 .. n_near-1, far rows behind them, both in row order
+    double ls = 0.0, ld = 0.0, fs = 0.0, fd = 0.0;                       // extents of the near rows / of the finite far rows
+    int base_near = 0, base_far = n_near;
+    for (int64_t it = 0; it < n; it += 256) {
+        const int64_t i = it + tid;
+        double a[3] = { 0, 0, 0 }, bb[3] = { 0, 0, 0 };
+        const bool live = i < n, near = live && row(i, a, bb);
+        const unsigned long long mn = __ballot(near), mf = __ballot(live && !near);
+        if (lane == 0) sh_cnt[wave] = __popcll(mn);
+        __syncthreads();
+        int before_near = 0, all_near = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before_near += sh_cnt[w]; all_near += sh_cnt[w]; }
+        const int rows_before = (int)(it < n ? ((n - it < 256 ? n - it : 256)) : 0);
+        const int live_before_wave = wave * 64 < rows_before ? wave * 64 : rows_before;     // live rows in the waves before this one
+        const int before_far = live_before_wave - before_near;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (live) {
+            const int slot = near ? base_near + before_near + __popcll(mn & below) : base_far + before_far + __popcll(mf & below);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                frows[(int64_t)c * total + i0 + slot] = (float)a[c];     // far rows too: screened against THEIR extent (NaN / inf stay what they are)
+                frows[(int64_t)(3 + c) * total + i0 + slot] = (float)bb[c];
+                if (near) { ls = fmax(ls, fabs(a[c])); ld = fmax(ld, fabs(bb[c])); }
+                else { if (fabs(a[c]) < 1e300) fs = fmax(fs, fabs(a[c])); if (fabs(bb[c]) < 1e300) fd = fmax(fd, fabs(bb[c])); }
+            }
+            ridx[i0 + slot] = (int32_t)i;
+        }
+        base_near += all_near; base_far += rows_before - all_near;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ls = fmax(ls, __shfl_xor(ls, o, 64)); ld = fmax(ld, __shfl_xor(ld, o, 64));
+        fs = fmax(fs, __shfl_xor(fs, o, 64)); fd = fmax(fd, __shfl_xor(fd, o, 64));
+    }
+    if (lane == 0) { sh_max[wave * 4] = ls; sh_max[wave * 4 + 1] = ld; sh_max[wave * 4 + 2] = fs; sh_max[wave * 4 + 3] = fd; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) { ls = fmax(ls, sh_max[w * 2]); ld = fmax(ld, sh_max[w * 2 + 1]); }
-        ls = fmax(ls, sh_max[0]); ld = fmax(ld, sh_max[1]);
-        for (int c = 0; c < 3; ++c) { fhdr[b * 8 + c] = x0[c]; fhdr[b * 8 + 3 + c] = y0[c]; }
-        fhdr[b * 8 + 6] = ls; fhdr[b * 8 + 7] = ld;
+        for (int w = 0; w < 4; ++w) { ls = fmax(ls, sh_max[w * 4]); ld = fmax(ld, sh_max[w * 4 + 1]); fs = fmax(fs, sh_max[w * 4 + 2]); fd = fmax(fd, sh_max[w * 4 + 3]); }
+        for (int c = 0; c < 3; ++c) { fhdr[b * RANSAC_HDR + c] = x0[c]; fhdr[b * RANSAC_HDR + 3 + c] = y0[c]; }
+        fhdr[b * RANSAC_HDR + 6] = ls; fhdr[b * RANSAC_HDR + 7] = ld; fhdr[b * RANSAC_HDR + 8] = (double)n_near;
+        fhdr[b * RANSAC_HDR + 9] = fs; fhdr[b * RANSAC_HDR + 10] = fd;
     }
+    (void)sh_near;
 }
-__device__ __forceinline__ bool ransac_rows_of_set(const float* __restrict__ frows, const double* __restrict__ fhdr, int64_t total, int64_t b, int64_t i0,
-                                                   RansacRows& rows)
+__device__ __forceinline__ bool ransac_rows_of_set(const float* __restrict__ frows, const int32_t* __restrict__ ridx, const double* __restrict__ fhdr,
+                                                   int64_t total, int64_t b, int64_t i0, RansacRows& rows)
 {
     if (!frows) return false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         rows.x[c] = frows + (int64_t)c * total + i0; rows.y[c] = frows + (int64_t)(3 + c) * total + i0;
-        rows.x0[c] = fhdr[b * 8 + c]; rows.y0[c] = fhdr[b * 8 + 3 + c];
+        rows.x0[c] = fhdr[b * RANSAC_HDR + c]; rows.y0[c] = fhdr[b * RANSAC_HDR + 3 + c];
     }
-    rows.Lsrc = fhdr[b * 8 + 6]; rows.Ldst = fhdr[b * 8 + 7];
+    rows.ridx = ridx + i0;
+    rows.Lsrc = fhdr[b * RANSAC_HDR + 6]; rows.Ldst = fhdr[b * RANSAC_HDR + 7]; rows.n_near = (int)fhdr[b * RANSAC_HDR + 8];
+    rows.Fsrc = fhdr[b * RANSAC_HDR + 9]; rows.Fdst = fhdr[b * RANSAC_HDR + 10];
     return rows.Lsrc == rows.Lsrc;                                           // NaN: not staged
 }
 
@@ -710,7 +800,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
     double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
-    int32_t* __restrict__ n_inliers, const float* __restrict__ frows, const double* __restrict__ fhdr, int64_t total)
+    int32_t* __restrict__ n_inliers, const float* __restrict__ frows, const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total)
 {
     __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
     __shared__ double sh_fit[13];
@@ -728,7 +818,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     bool bad_index = false;
     unsigned long long key;
     RansacRows rows;
-    if (ransac_rows_of_set(frows, fhdr, total, b, i0, rows)) {               // block-uniform
+    if (ransac_rows_of_set(frows, ridx, fhdr, total, b, i0, rows)) {         // block-uniform
         key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
     } else {
         key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
@@ -748,7 +838,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
 __global__ __launch_bounds__(64) void ransac_scan_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
                                                          const int32_t* __restrict__ counts, const int32_t* __restrict__ sample_idx, int trials, int ms,
                                                          double thr, unsigned long long* __restrict__ keys, const float* __restrict__ frows,
-                                                         const double* __restrict__ fhdr, int64_t total)
+                                                         const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total)
 {
     const int64_t b = blockIdx.y;
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
@@ -758,7 +848,7 @@ __global__ __launch_bounds__(64) void ransac_scan_kernel(const double* __restric
     const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
     unsigned long long key;
     RansacRows rows;
-    if (ransac_rows_of_set(frows, fhdr, total, b, i0, rows)) {
+    if (ransac_rows_of_set(frows, ridx, fhdr, total, b, i0, rows)) {
         key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, tr, tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
     } else {
         key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tr, tr < trials ? tr + 1 : tr, 1, ms, thr, bad_index));
@@ -828,28 +918,28 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
     // residual counts screened in packed single precision with an exact double re-check inside the error band (the counts are the
     // double kernel's); needs the rows as floats in the workspace, hence their total number (0 = unknown to the host: double
     // throughout, as with gsf_set_option "k2b_screen" 0)
-    const float* frows = nullptr; const double* fhdr = nullptr;
+    const float* frows = nullptr; const double* fhdr = nullptr; const int32_t* ridx = nullptr;
     if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows <= ((int64_t)1 << 31) && trials >= 64) {
-        const size_t hdr_bytes = ((size_t)B * 64 + 255) & ~(size_t)255;
-        const int rc = ensure_k2b_scratch(ctx, hdr_bytes + (size_t)total_rows * 24);
+        const size_t hdr_bytes = ((size_t)B * RANSAC_HDR * 8 + 255) & ~(size_t)255;
+        const int rc = ensure_k2b_scratch(ctx, hdr_bytes + (size_t)total_rows * 28);
         if (rc) return rc;
-        double* h = (double*)ctx->k2b_scratch; float* f = (float*)((char*)ctx->k2b_scratch + hdr_bytes);
-        hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, h);
-        frows = f; fhdr = h;
+        double* h = (double*)ctx->k2b_scratch; float* f = (float*)((char*)ctx->k2b_scratch + hdr_bytes); int32_t* ri = (int32_t*)(f + (size_t)total_rows * 6);
+        hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, ri, h);
+        frows = f; fhdr = h; ridx = ri;
     }
     if (B <= RANSAC_SPLIT_MAX_SETS && trials >= 256) {
         // few sets: hypotheses spread over the chip, then one finishing block per set
         unsigned long long* keys = (unsigned long long*)ctx->small_scratch;
         GSF_HIP(hipMemsetAsync(keys, 0, (size_t)B * 16, ctx->stream));
         hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
-                           sample_idx, (int)trials, (int)min_samples, thr, keys, frows, fhdr, total_rows);
+                           sample_idx, (int)trials, (int)min_samples, thr, keys, frows, ridx, fhdr, total_rows);
         hipLaunchKernelGGL(ransac_finish_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
                            (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
     }
     hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
-                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers, frows, fhdr, total_rows);
+                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers, frows, ridx, fhdr, total_rows);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -1233,7 +1233,7 @@ def test_k2b_single_precision_screen_keeps_the_double_counts(B):
     """K2b counts the inliers of every hypothesis with a packed single-precision screen and re-checks in double every row inside the
     rounding band (csrc/gsf_sim3.hip): counts, masks, fits and statuses must be those of the all-double count -- also with rows planted
     from nanometres to centimetres off the threshold sphere, a threshold inside the noise, one tiny enough that the band swallows it,
-    a NaN row, a wild row 5 000 km away (which blows the set's error bound up and sends everything to the double path), and for one
+    a NaN row, wild rows 5 000 km away (set apart and screened with a band of their own), a set that starts with wild rows, and for one
     set (hypotheses spread over single-wave blocks) as well as many."""
     import torch
     rng = np.random.default_rng(12)
@@ -1250,6 +1250,7 @@ def test_k2b_single_precision_screen_keeps_the_double_counts(B):
             d[b_, rows] += torch.as_tensor(u * (thr + rng.normal(size=(band_rows, 1)) * 10.0 ** rng.uniform(-9, -2, size=(band_rows, 1))), device="cuda")
         if wild:
             d[0, 7] = 0.0; d[min(1, nt - 1), 9, 1] = float("nan")
+            d[min(2, nt - 1), 0] = 0.0; d[min(3, nt - 1), :40] = 0.0     # a set that STARTS with a wild row; one whose first 40 rows (three of the five probes) are wild
         offs = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device="cuda")
         idx = torch.as_tensor(np.stack([np.stack([rng.permutation(npts)[:4] for _ in range(trials)]) for _ in range(nt)]).astype(np.int32)).cuda()
         res = {}

@@ -19,10 +19,12 @@ dev = "cuda"
 _r = np.random.default_rng(0)
 
 
-def case(nt, npts, trials, thr, band_rows=0, seed=3):
+def case(nt, npts, trials, thr, band_rows=0, seed=3, zero_fill=False):
     bt = B.TrajectoryBatch.synthetic(nt, npts, layout=B.LAYOUT_TRAJ_MAJOR, seed=seed)
     src = bt.pos.reshape(nt * npts, 3).contiguous(); g3 = bt.gps.reshape(nt * npts, 3)
     dst = torch.where(torch.isnan(g3), bt.pos.reshape(nt * npts, 3) + g3[0:1].nan_to_num(0.0) * 0.0 + torch.nanmean(g3 - bt.pos.reshape(nt * npts, 3), dim=0, keepdim=True), g3).contiguous()   # missing fixes: a plausible point (zeros would be 5 000 km away)
+    if zero_fill:
+        dst = torch.nan_to_num(g3, nan=0.0).contiguous()                  # the aux bench's input up to round 3: missing fixes 5 000 km away
     if band_rows:
         # rows pushed to within micrometres .. millimetres of the threshold sphere of the TRUE alignment: the screen must hand them on
         d = dst.reshape(nt, npts, 3)
@@ -40,13 +42,15 @@ def case(nt, npts, trials, thr, band_rows=0, seed=3):
         out = B.sim3_ransac_batch(src, dst, offs, idx, thr, 4)
         res[scr] = [o.cpu().numpy() for o in out] + [timed(lambda: B.sim3_ransac_batch(src, dst, offs, idx, thr, 4), reps=3)]
     B.context().set_option("k2b_screen", 1)
+    zf = ' zero-filled' if zero_fill else ''
     same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res[1][:-1], res[0][:-1]))
-    print(f"{nt:5d} sets x {npts:4d} rows x {trials:4d} trials thr {thr:g} band rows {band_rows:3d}: screened {res[1][-1] * 1e3:8.1f} us  double {res[0][-1] * 1e3:8.1f} us  identical {same}", flush=True)
+    print(f"{nt:5d} sets x {npts:4d} rows x {trials:4d} trials thr {thr:g} band rows {band_rows:3d}{zf}: screened {res[1][-1] * 1e3:8.1f} us  double {res[0][-1] * 1e3:8.1f} us  identical {same}", flush=True)
     return same
 
 
 ok = True
 ok &= case(1000, 271, 1000, 4.0)
+ok &= case(1000, 271, 1000, 4.0, zero_fill=True)
 ok &= case(1000, 271, 1000, 4.0, band_rows=40)
 ok &= case(1000, 271, 1000, 0.05)                 # threshold inside the noise: many rows near it
 ok &= case(1000, 271, 1000, 1e-4)                 # band wider than the threshold: everything re-checked

@@ -52,10 +52,7 @@ del pos, quat
 # ---- K2b: RANSAC, 1000 trajectories x 271 points x 1000 trials (C2-shaped)
 nt, npts, trials = 1000, 271, 1000
 bt = B.TrajectoryBatch.synthetic(nt, npts, layout=B.LAYOUT_TRAJ_MAJOR, seed=3)
-srcp = bt.pos.reshape(nt * npts, 3).contiguous(); _g3 = bt.gps.reshape(nt * npts, 3)
-# missing fixes become a plausible point (the chains compact them away; a zero row would sit 5 000 km from the track and blow up the
-# rounding bound of K2b's single-precision screen for its whole set)
-dstp = torch.where(torch.isnan(_g3), srcp + torch.nanmean(_g3 - srcp, dim=0, keepdim=True), _g3).contiguous()
+srcp = bt.pos.reshape(nt * npts, 3).contiguous(); dstp = torch.nan_to_num(bt.gps.reshape(nt * npts, 3), nan=0.0).contiguous()   # missing fixes zero-filled (as in rounds 1-2)
 offr = torch.arange(0, nt * npts + 1, npts, dtype=torch.int64, device=dev)
 _r = np.random.default_rng(0)                                            # (host-made index sets: torch.randperm crashes under rocprofv3 --pmc)
 idx = torch.as_tensor(np.stack([np.stack([_r.permutation(npts)[:4] for _ in range(trials)]) for _ in range(8)]).astype(np.int32)).to(dev)
