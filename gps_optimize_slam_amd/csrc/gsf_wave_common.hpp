@@ -196,6 +196,10 @@ __device__ __forceinline__ int32_t* gsf_stamp_buf() { __shared__ int32_t buf[64]
 #define GSF_STATUS_PTR(a) ((a).status)
 #endif
 
+#ifndef GSF_WIDE_STORES
+#define GSF_WIDE_STORES 1                                                 // big-batch builds store whole output slabs through LDS (see the chunk loop's store site)
+#endif
+
 struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
 
 // pose i of one trajectory (clamped to the last pose for the idle lanes of the final chunk): one contiguous slab per array
@@ -765,7 +769,28 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         cP[0] = lane_bcast(Pf[0], L); cP[1] = lane_bcast(Pf[1], L); cP[2] = lane_bcast(Pf[2], L);
         c_po = lane_bcast(p, L); c_r = lane_bcast(r, L); c_ok = ((ok_mask >> L) & 1ull) != 0ull; c_t = lane_bcast(t, L);
         chunk_arrived(nxt);                                              // the next chunk's rows; then this chunk's stores
-        if (active) {
+        if (GSF_WIDE_STORES && !SMALLBATCH) {
+            // Many waves per SIMD (C3-sized batches): the launch sits on the memory system under its mixed read + write stream, and
+            // 8-byte stores at 24 / 32-byte stride leave L2 as incomplete lines (counter writes 1.11x the bytes).  The chunk's two output
+            // slabs are contiguous (rows x 24 and rows x 32 bytes): the wave lays its rows out in LDS and stores the slabs as whole
+            // 16-byte pieces, lane after lane -- four stores of a kilobyte each instead of seven strided ones.  A lone wave (C2) would
+            // pay the LDS round trip on its critical path, so the small-batch build keeps the direct stores.
+            __shared__ double gsf_out_stage[64 * 7];
+            typedef double gsf_d2 __attribute__((ext_vector_type(2), aligned(8)));
+            gsf_out_stage[lane * 3] = o0; gsf_out_stage[lane * 3 + 1] = o1; gsf_out_stage[lane * 3 + 2] = o2;
+            gsf_out_stage[192 + lane * 4] = qi.x; gsf_out_stage[192 + lane * 4 + 1] = qi.y; gsf_out_stage[192 + lane * 4 + 2] = qi.z; gsf_out_stage[192 + lane * 4 + 3] = qi.w;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // one wave per block: its LDS operations complete in order, no barrier
+            const int rows = L + 1, ppieces = (rows * 3) / 2, qpieces = rows * 2;
+            const gsf_d2* sv = (const gsf_d2*)gsf_out_stage;
+            gsf_d2* ps = (gsf_d2*)(pob + c0 * 3); gsf_d2* qs = (gsf_d2*)(qob + c0 * 4);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pc = lane + 64 * k;
+                if (pc < ppieces) __builtin_nontemporal_store(sv[pc], &ps[pc]);
+                if (pc < qpieces) __builtin_nontemporal_store(sv[96 + pc], &qs[pc]);
+            }
+            if ((rows & 1) && lane == 0) __builtin_nontemporal_store(gsf_out_stage[rows * 3 - 1], &pob[(c0 + rows) * 3 - 1]);   // odd row count: the slab ends on half a piece
+        } else if (active) {
             // streaming stores: the fused rows are not read again (except by the rare carried-outage fix-up, which stays
             // coherent through L2), so they should not wait in L2 for the end-of-kernel write-back
             __builtin_nontemporal_store(o0, &pob[i * 3]); __builtin_nontemporal_store(o1, &pob[i * 3 + 1]); __builtin_nontemporal_store(o2, &pob[i * 3 + 2]);
