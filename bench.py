@@ -507,7 +507,7 @@ def worker(args):
                                   "layout": "trajectory-major AoS (wave-per-trajectory scans)", "step": "one pass over the shard: per chunk fused pipeline"
                                   + (" + all-gather of the chunk's poses (second stream, overlapped)" if world > 1 else ""),
                                   "parallelism": f"trajectory-sharded x{world}" + (" (gloo rehearsal on shared GPUs)" if rehearsal else "")},
-                          roofline={"bound": "hbm", "kernel": "ekf_wave_kernel<true, false, 1>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          roofline={"bound": "hbm", "kernel": "ekf_wave_big_kernel<true, 1>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": co["hbm_frac"], "traffic": None, "traffic_note": "no PMC pass at this size", "alg_bytes_per_launch": info["chunk_trajectories"] * N * ALG_BYTES_PER_POSE,
                                     "kernel_ms": co["ms"] / info["chunks"]},
                           c5=info)
@@ -609,7 +609,9 @@ def worker(args):
         kernel_name, grid_threads = "ekf_wave_duo_kernel<true, 1>", Bn * 128                     # a helper wave per trajectory
     else:
         # <PIPELINE, SMALLBATCH, AXMODE>: AXMODE 1 = x and y share their noise figures, z does not (the default CONFIG, compiled-in scans)
-        kernel_name, grid_threads = "ekf_wave_kernel<%s, %s, 1>" % ("true" if pipe else "false", "true" if Bn <= 2048 else "false"), Bn * 64
+        # small batches: ekf_wave_kernel<PIPELINE, true, 1> (gsf_ekf_wave.hip); more than two waves per SIMD: ekf_wave_big_kernel<PIPELINE, 1>
+        kernel_name = ("ekf_wave_kernel<%s, true, 1>" if Bn <= 2048 else "ekf_wave_big_kernel<%s, 1>") % ("true" if pipe else "false")
+        grid_threads = Bn * 64
     wl_key = args.workload + ("" if pipe else "ekf") if not blk else args.workload + "block" + ("" if pipe else "ekf")   # section of the PMC profile
     traffic, traffic_src = profiled_traffic(wl_key, kernel_name, grid_threads)
     result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,

@@ -22,14 +22,14 @@ using namespace gsf;
 
 namespace {
 
-// AXMODE 1: x and y share (P0, Q, R), z does not (checked by the launcher; the default CONFIG) -- see wave_serial_chunks
-#ifndef GSF_BIG_OCC
-#define GSF_BIG_OCC 1
-#endif
-#define GSF_BIG_OCC_EXPR (SMALLBATCH ? 1 : GSF_BIG_OCC)
+// AXMODE 1: x and y share (P0, Q, R), z does not (checked by the launcher; the default CONFIG) -- see wave_serial_chunks.
+// This file holds the SMALL-batch builds (inlined cold blocks, direct loads and stores; scheduled with iterative-ilp for the lone wave);
+// the big-batch builds of the same template live in gsf_ekf_wave_big.hip (slab loads / stores through LDS, scheduled with max-ilp:
+// iterative-ilp crashes clang's register allocator on them, and max-ilp is the faster of the two at many waves per SIMD anyway).
 template <bool PIPELINE, bool SMALLBATCH, int AXMODE>
-__global__ __launch_bounds__(64, GSF_BIG_OCC_EXPR) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
+__global__ __launch_bounds__(64, 1) void ekf_wave_kernel(WaveArgs a, EkfConfig cfg)
 {
+    static_assert(SMALLBATCH, "big-batch instantiations belong to gsf_ekf_wave_big.hip");
     wave_serial_body<PIPELINE, false, SMALLBATCH, 1, AXMODE>(a, cfg, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
@@ -58,17 +58,6 @@ __global__ __launch_bounds__(128) void ekf_wave_duo_kernel(WaveArgs a, EkfConfig
         return;
     }
     wave_serial_body<PIPELINE, true, true, 1, AXMODE>(a, cfg, b, lane, gsf_pv, pv_stride);
-}
-
-EkfConfig to_core(const gsf_ekf_config* c)
-{
-    EkfConfig k;
-    for (int i = 0; i < 7; ++i) { k.P0[i] = c->initial_cov_diag[i]; k.Qps[i] = c->process_noise_diag[i]; }
-    for (int i = 0; i < 3; ++i) k.Rm[i] = c->meas_noise_diag[i];
-    k.yaw_thr_rad = c->sharp_turn_yaw_rate_threshold_deg_per_sec * (M_PI / 180.0);
-    k.sharp_turn_steps = c->default_ekf_transition_steps_on_sharp_turn;
-    k._pad = 0;
-    return k;
 }
 
 }  // namespace
@@ -107,11 +96,11 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     {
         // up to 2 048 waves (two per SIMD) the build with inlined cold blocks costs no occupancy; same arithmetic, same bits
         const bool small = B <= 2048;
-#define GSF_LAUNCH_WAVE(P_, S_, X_) hipLaunchKernelGGL((ekf_wave_kernel<P_, S_, X_>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k)
-        if (pipeline) { if (small) { if (xy) GSF_LAUNCH_WAVE(true, true, 1); else GSF_LAUNCH_WAVE(true, true, 0); }
-                        else { if (xy) GSF_LAUNCH_WAVE(true, false, 1); else GSF_LAUNCH_WAVE(true, false, 0); } }
-        else { if (small) { if (xy) GSF_LAUNCH_WAVE(false, true, 1); else GSF_LAUNCH_WAVE(false, true, 0); }
-               else { if (xy) GSF_LAUNCH_WAVE(false, false, 1); else GSF_LAUNCH_WAVE(false, false, 0); } }
+        if (!small)
+            return launch_ekf_wave_big(ctx, pipeline, xy, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status, offsets);
+#define GSF_LAUNCH_WAVE(P_, X_) hipLaunchKernelGGL((ekf_wave_kernel<P_, true, X_>), dim3((unsigned)B), dim3(64), 0, ctx->stream, a, k)
+        if (pipeline) { if (xy) GSF_LAUNCH_WAVE(true, 1); else GSF_LAUNCH_WAVE(true, 0); }
+        else { if (xy) GSF_LAUNCH_WAVE(false, 1); else GSF_LAUNCH_WAVE(false, 0); }
 #undef GSF_LAUNCH_WAVE
     }
     GSF_HIP(hipGetLastError());

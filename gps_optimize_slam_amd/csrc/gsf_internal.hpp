@@ -73,6 +73,11 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
                     int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
                     const int64_t* offsets = nullptr);
 
+// the big-batch builds of the wave kernels (gsf_ekf_wave_big.hip): B > 2 048
+int launch_ekf_wave_big(gsf_ctx* ctx, bool pipeline, bool xy, const double* ts, const double* pos, const double* quat, const double* gps,
+                        const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B, int64_t N,
+                        double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status, const int64_t* offsets);
+
 // workgroup-per-trajectory K4 / fused pipeline (gsf_ekf_block.hip): one wave per 64-pose chunk, every input byte read once
 bool ekf_block_applies(int64_t N, const int64_t* offsets);
 int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,

@@ -73,9 +73,11 @@ GSF_HD double seed_rsqrt(double a)
 }
 
 // Rotation.from_quat: q/|q|; false if the norm is 0/NaN/inf (SciPy raises ValueError).
+// x^2 + y^2 + z^2 + w^2 as ONE chain (see quat_mul: a sum of products has no fixed rounding under -ffp-contract=fast)
+GSF_HD double quat_norm2(const Quat& q) { return fma(q.w, q.w, fma(q.z, q.z, fma(q.y, q.y, q.x * q.x))); }
 GSF_HD bool quat_unit(const Quat& q, Quat& o)
 {
-    double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    double n2 = quat_norm2(q);
     bool ok = (n2 >= 1e-280) && (n2 <= 1e280);     // sqrt(n2) > 0 and finite; the margins keep fast_rsqrt in its normal range
     double r = fast_rsqrt(ok ? n2 : 1.0);
     o.x = q.x * r; o.y = q.y * r; o.z = q.z * r; o.w = q.w * r;
@@ -85,22 +87,27 @@ GSF_HD Quat quat_conj(const Quat& q) { return Quat{ -q.x, -q.y, -q.z, q.w }; }
 // Rotation.__mul__ (Hamilton product p*q, "q first")
 GSF_HD Quat quat_mul(const Quat& p, const Quat& q)
 {
+    // Written as explicit fma chains: under -ffp-contract=fast the compiler is free to fuse "a*b + c*d + ..." in ANY association, and it
+    // picked different ones for the scalar part in two builds of the same kernel (the big-batch build that fetches rows through LDS vs
+    // the small-batch one: 1 ulp in q.w on ~0.01 % of the rows, which broke the bit-equality of a batch and its shards).  With the chain
+    // spelled out there is one result.
     Quat o;
-    o.x = p.w * q.x + q.w * p.x + (p.y * q.z - p.z * q.y);
-    o.y = p.w * q.y + q.w * p.y + (p.z * q.x - p.x * q.z);
-    o.z = p.w * q.z + q.w * p.z + (p.x * q.y - p.y * q.x);
-    o.w = p.w * q.w - (p.x * q.x + p.y * q.y + p.z * q.z);
+    o.x = fma(p.w, q.x, fma(q.w, p.x, fma(p.y, q.z, -(p.z * q.y))));
+    o.y = fma(p.w, q.y, fma(q.w, p.y, fma(p.z, q.x, -(p.x * q.z))));
+    o.z = fma(p.w, q.z, fma(q.w, p.z, fma(p.x, q.y, -(p.y * q.x))));
+    o.w = fma(p.w, q.w, -fma(p.z, q.z, fma(p.y, q.y, p.x * q.x)));
     return o;
 }
 // Rotation.apply for a unit quaternion: as_matrix() @ v
 GSF_HD Vec3 quat_rotate(const Quat& q, const Vec3& v)
 {
     // M(q) v for a UNIT q in the cross-product form v + w t + u x t, t = 2 u x v (18 flops instead of 39 for the matrix)
-    double tx = 2.0 * (q.y * v.z - q.z * v.y), ty = 2.0 * (q.z * v.x - q.x * v.z), tz = 2.0 * (q.x * v.y - q.y * v.x);
+    // (explicit chains, as in quat_mul)
+    const double tx = 2.0 * fma(q.y, v.z, -(q.z * v.y)), ty = 2.0 * fma(q.z, v.x, -(q.x * v.z)), tz = 2.0 * fma(q.x, v.y, -(q.y * v.x));
     Vec3 o;
-    o.x = v.x + q.w * tx + (q.y * tz - q.z * ty);
-    o.y = v.y + q.w * ty + (q.z * tx - q.x * tz);
-    o.z = v.z + q.w * tz + (q.x * ty - q.y * tx);
+    o.x = fma(q.w, tx, v.x) + fma(q.y, tz, -(q.z * ty));
+    o.y = fma(q.w, ty, v.y) + fma(q.z, tx, -(q.x * tz));
+    o.z = fma(q.w, tz, v.z) + fma(q.x, ty, -(q.y * tx));
     return o;
 }
 // as_matrix() of a unit quaternion (SciPy's form: m00 = x^2 - y^2 - z^2 + w^2, m10 = 2(xy + zw), ...).  Returned by value with
@@ -123,7 +130,7 @@ GSF_HD double quat_yaw_zyx(const Quat& q)
 // ExtendedKalmanFilter.normalize_quaternion, ref :697-700
 GSF_HD Quat ekf_normalize(const Quat& q)
 {
-    double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    double n2 = quat_norm2(q);
     bool ok = (n2 > 1e-18) && (n2 <= 1e280);       // norm > 1e-9 (ref :699); NaN/inf fall through to the identity like NaN > 1e-9
     double r = fast_rsqrt(ok ? n2 : 1.0);
     return ok ? Quat{ q.x * r, q.y * r, q.z * r, q.w * r } : Quat{ 0.0, 0.0, 0.0, 1.0 };
@@ -131,7 +138,7 @@ GSF_HD Quat ekf_normalize(const Quat& q)
 // quaternion_nlerp, ref :94-105
 GSF_HD Quat quat_nlerp(const Quat& q1, Quat q2, double weight_q2)
 {
-    double dot = q1.x * q2.x + q1.y * q2.y + q1.z * q2.z + q1.w * q2.w;
+    double dot = fma(q1.w, q2.w, fma(q1.z, q2.z, fma(q1.y, q2.y, q1.x * q2.x)));
     if (dot < 0.0) { q2.x = -q2.x; q2.y = -q2.y; q2.z = -q2.z; q2.w = -q2.w; }
     double w = fmin(fmax(weight_q2, 0.0), 1.0);
     Quat qi{ (1.0 - w) * q1.x + w * q2.x, (1.0 - w) * q1.y + w * q2.y, (1.0 - w) * q1.z + w * q2.z,

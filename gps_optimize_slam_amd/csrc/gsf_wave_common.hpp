@@ -200,6 +200,17 @@ __device__ __forceinline__ int32_t* gsf_stamp_buf() { __shared__ int32_t buf[64]
 #define GSF_WIDE_STORES 1                                                 // big-batch builds store whole output slabs through LDS (see the chunk loop's store site)
 #endif
 
+inline EkfConfig to_core(const gsf_ekf_config* c)
+{
+    EkfConfig k;
+    for (int i = 0; i < 7; ++i) { k.P0[i] = c->initial_cov_diag[i]; k.Qps[i] = c->process_noise_diag[i]; }
+    for (int i = 0; i < 3; ++i) k.Rm[i] = c->meas_noise_diag[i];
+    k.yaw_thr_rad = c->sharp_turn_yaw_rate_threshold_deg_per_sec * (M_PI / 180.0);
+    k.sharp_turn_steps = c->default_ekf_transition_steps_on_sharp_turn;
+    k._pad = 0;
+    return k;
+}
+
 struct ChunkIn { double t; Vec3 p; Quat q; Vec3 z; uint32_t v; };
 
 // pose i of one trajectory (clamped to the last pose for the idle lanes of the final chunk): one contiguous slab per array
@@ -229,6 +240,69 @@ __device__ __forceinline__ void chunk_arrived(const ChunkIn& c)
 {
     asm volatile("" :: "v"(c.t), "v"(c.p.x), "v"(c.p.y), "v"(c.p.z), "v"(c.q.x), "v"(c.q.y), "v"(c.q.z), "v"(c.q.w), "v"(c.z.x), "v"(c.z.y), "v"(c.z.z), "v"(c.v) : "memory");
 }
+
+// ---- the same rows fetched as WHOLE SLABS (big-batch builds).  pos / quat / gps rows are 24 / 32 / 24 bytes apart, so a lane's 8-byte
+// loads of its own row are strided; the chunk's slab of each array is contiguous (rows x 24 / 32 / 24 bytes), and the wave fetches it as
+// 16-byte pieces, lane after lane (2 + 2 + 2 loads of a kilobyte instead of 3 + 4 + 3 strided ones), parks the pieces in LDS when the
+// chunk is consumed and every lane picks its row up from there.  Stamps and mask bytes are contiguous per lane already.  Pieces past the
+// end of a short last chunk are clamped onto its last 16 bytes (same bytes written to the same LDS place twice), idle lanes read the
+// last row -- what the per-lane loads' clamping did.  Same values in the same registers afterwards: bit-identical results.
+#ifndef GSF_WIDE_LOADS
+#define GSF_WIDE_LOADS 1
+#endif
+typedef double gsf_v2 __attribute__((ext_vector_type(2), aligned(8)));
+struct ChunkWide { double t; gsf_v2 P[2], Q[2], Z[2]; uint32_t v; };
+__device__ __forceinline__ int wide_piece_off(const int piece, const int slab_bytes) { const int o = piece * 16; return o < slab_bytes - 16 ? o : slab_bytes - 16; }
+__device__ __forceinline__ ChunkWide load_chunk_wide(const double* __restrict__ tsb, const double* __restrict__ posb, const double* __restrict__ quatb,
+                                                     const double* __restrict__ gpsb, const uint8_t* __restrict__ valb, int64_t c0n, const int lane,
+                                                     const int64_t N)
+{
+    if (c0n >= N) c0n = (N - 1) & ~(int64_t)63;                          // the prefetch issued by the last chunk: any rows of the track, never used
+    const int rows = (int)(N - c0n < 64 ? N - c0n : 64);
+    const int64_t il = c0n + lane < N ? c0n + lane : N - 1;
+    ChunkWide w;
+    w.t = __builtin_nontemporal_load(&tsb[il]);
+    w.v = __builtin_nontemporal_load(&valb[il]);
+    const char* pb = (const char*)(posb + c0n * 3); const char* qb = (const char*)(quatb + c0n * 4); const char* zb = (const char*)(gpsb + c0n * 3);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pc = lane + 64 * k;
+        w.P[k] = __builtin_nontemporal_load((const gsf_v2*)(pb + wide_piece_off(pc, rows * 24)));
+        w.Q[k] = __builtin_nontemporal_load((const gsf_v2*)(qb + wide_piece_off(pc, rows * 32)));
+        w.Z[k] = __builtin_nontemporal_load((const gsf_v2*)(zb + wide_piece_off(pc, rows * 24)));
+    }
+    return w;
+}
+__device__ __forceinline__ void chunk_arrived(const ChunkWide& c)
+{
+    asm volatile("" :: "v"(c.t), "v"(c.P[0]), "v"(c.P[1]), "v"(c.Q[0]), "v"(c.Q[1]), "v"(c.Z[0]), "v"(c.Z[1]), "v"(c.v) : "memory");
+}
+// the pieces of the chunk whose last active lane is L, parked in `stage` (64 x 10 doubles of LDS, this wave's own) and picked up row by row
+__device__ __forceinline__ ChunkIn unpack_chunk(const ChunkWide& w, double* stage, const int lane, const int L)
+{
+    const int rows = L + 1;
+    char* sp = (char*)stage; char* sq = sp + 64 * 24; char* sz = sq + 64 * 32;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pc = lane + 64 * k;
+        *(gsf_v2*)(sp + wide_piece_off(pc, rows * 24)) = w.P[k];
+        *(gsf_v2*)(sq + wide_piece_off(pc, rows * 32)) = w.Q[k];
+        *(gsf_v2*)(sz + wide_piece_off(pc, rows * 24)) = w.Z[k];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // one wave per block: its LDS operations complete in order, no barrier
+    const int r = lane < L ? lane : L;
+    const double* dp = (const double*)sp + r * 3; const double* dq = (const double*)sq + r * 4; const double* dz = (const double*)sz + r * 3;
+    ChunkIn c;
+    c.t = w.t; c.v = w.v;
+    c.p = Vec3{ dp[0], dp[1], dp[2] };
+    c.q = Quat{ dq[0], dq[1], dq[2], dq[3] };
+    c.z = Vec3{ dz[0], dz[1], dz[2] };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // ... and the reads are back before the next chunk's pieces overwrite the stage
+    return c;
+}
+template <bool WIDE> struct NextChunk { typedef ChunkIn type; };
+template <> struct NextChunk<true> { typedef ChunkWide type; };
+#define GSF_WIDE(SMALLBATCH_) (GSF_WIDE_LOADS && !(SMALLBATCH_))
 
 // Second half of the fused fit: wave totals of the per-lane partial moments (shifted by as_ / bs_), Umeyama closed form, R/t/s
 // outputs, Sim3 of pose 0 (ref :439-451, :464-466).  Returns false -- after writing NaN rows and the status word -- when the fit
@@ -488,7 +562,8 @@ template <> struct RingStore<0> {
 // code that the scheduler can interleave (a lone wave issues dependent FP64 / DPP work every 6-7 cycles, independent work every 4.5).
 template <bool PIPELINE, bool PREVAR = false, bool SMALLBATCH = false, int RINGS = 1, int AXMODE = 0>
 __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfConfig& cfg, const int64_t b, const int lane, const int64_t base,
-                                                   const int64_t N, const Vec3& p0, const Quat& q0, const int32_t fit, ChunkIn nxt,
+                                                   const int64_t N, const Vec3& p0, const Quat& q0, const int32_t fit,
+                                                   typename NextChunk<GSF_WIDE(SMALLBATCH)>::type nxt,
                                                    const double* pv = nullptr, const int pv_stride = 0, const int ring_slot = 0,
                                                    double* ext_ring = nullptr)
 {
@@ -520,8 +595,16 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
     GSF_STAMP(7);
     // "previous original pose" of pose 0 is pose 0 itself (ref :858): taken from lane 0 of the chunk that has just arrived
     bool c_prev_avail = __builtin_amdgcn_readlane((int)nxt.v, 0) != 0;   // ref :848 (raw mask)
-    Vec3 c_po = lane_bcast(nxt.p, 0);
-    Quat c_r; bool c_ok = quat_unit(lane_bcast(nxt.q, 0), c_r);
+    Vec3 c_po; Quat c_q0;
+    if constexpr (GSF_WIDE(SMALLBATCH)) {
+        // (the slab pieces hold pose 0 across lanes 0 and 1; these wave-uniform rows come through the scalar cache instead, other waves
+        // cover the round trip in the big-batch build)
+        c_po = Vec3{ posb[0], posb[1], posb[2] };
+        c_q0 = Quat{ a.quat[base * 4], a.quat[base * 4 + 1], a.quat[base * 4 + 2], a.quat[base * 4 + 3] };
+    } else {
+        c_po = lane_bcast(nxt.p, 0); c_q0 = lane_bcast(nxt.q, 0);
+    }
+    Quat c_r; bool c_ok = quat_unit(c_q0, c_r);
     double c_t = lane_bcast(nxt.t, 0);
     int32_t status = c_prev_avail ? 0 : ST_HAD_OUTAGE;
     // Orientation on the fast path.  With every quaternion valid the increments telescope to q_i = Cq r_i, Cq = q_carry conj(r_carry),
@@ -544,8 +627,15 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         const bool stepping = __builtin_amdgcn_inverse_ballot_w64(step_m);
         // ---- this chunk's poses were loaded one iteration ago; issue the loads of the NEXT 64 poses now so that their
         // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
-        const ChunkIn in = nxt;
-        nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);   // unconditional (clamped to the last row past the end): no branch between the loads and the arithmetic below
+        ChunkIn in;
+        if constexpr (GSF_WIDE(SMALLBATCH)) {
+            __shared__ double gsf_in_stage[64 * 10];
+            in = unpack_chunk(nxt, gsf_in_stage, lane, L);
+            nxt = load_chunk_wide(tsb, posb, quatb, gpsb, valb, c0 + 64, lane, N);
+        } else {
+            in = nxt;
+            nxt = load_chunk(tsb, posb, quatb, gpsb, valb, c0 + 64 + lane, N);   // unconditional (clamped to the last row past the end): no branch between the loads and the arithmetic below
+        }
         const double t = in.t;
         const Vec3 p = in.p; const Quat q = in.q; const Vec3 z = in.z;
         const u64 vraw_m = __ballot(in.v != 0);
@@ -817,7 +907,9 @@ __device__ __forceinline__ void wave_serial_body(const WaveArgs& a, const EkfCon
     const uint8_t* __restrict__ valb = a.valid + base;
 
     // the first 64 poses are requested before the prelude (fit / initial pose), whose latency then covers theirs
-    ChunkIn nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
+    typename NextChunk<GSF_WIDE(SMALLBATCH)>::type nxt;
+    if constexpr (GSF_WIDE(SMALLBATCH)) nxt = load_chunk_wide(tsb, posb, quatb, gpsb, valb, 0, lane, N);
+    else nxt = load_chunk(tsb, posb, quatb, gpsb, valb, lane, N);
     __builtin_amdgcn_sched_barrier(0);                                   // ... and stay requested HERE: nothing of the prelude is scheduled above them
     Vec3 p0; Quat q0; int32_t fit = 0;
     if (!wave_prelude<PIPELINE>(a, b, base, N, lane, p0, q0, fit)) {

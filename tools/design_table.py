@@ -17,9 +17,9 @@ HBM = 8000.0
 # (file, kernel as rocprof names it, grid threads) -> (row label, units, algorithmic bytes per launch, unit name)
 ROWS = [
     ("bench_default", "ekf_wave_kernel<true, true, 1>", 64000, "**C2 1 000 x 271 (bench default), fused pipeline**", 271_000, 271_000 * 145, "poses"),
-    ("bench_default", "ekf_wave_kernel<true, false, 1>", 6400000, "C3 100 000 x 1 000, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
-    ("bench_default", "ekf_wave_kernel<false, false, 1>", 6400000, "C3, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
-    ("bench_default", "ekf_wave_kernel<true, false, 1>", 2097152, "C5 shard chunk 32 768 x 1 000 (38 per pass), fused pipeline", 32_768_000, 32_768_000 * 145, "poses"),
+    ("bench_default", "ekf_wave_big_kernel<true, 1>", 6400000, "C3 100 000 x 1 000, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
+    ("bench_default", "ekf_wave_big_kernel<false, 1>", 6400000, "C3, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
+    ("bench_default", "ekf_wave_big_kernel<true, 1>", 2097152, "C5 shard chunk 32 768 x 1 000 (38 per pass), fused pipeline", 32_768_000, 32_768_000 * 145, "poses"),
     ("bench_default", "fuse_pipeline_kernel<1, 2, 2>", 1245184, "C5 shard 1 245 184 x 1 000 time-major, lane per trajectory, fused pipeline", 1_245_184_000, 1_245_184_000 * 145, "poses"),
     ("bench_default", "fuse_pipeline_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_fuse_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, K4 only", 100_000_000, 100_000_000 * 145, "poses"),

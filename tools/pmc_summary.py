@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files per kernel (sum over dispatches / n dispatches).
 usage: python tools/pmc_summary.py <dir-with-pmc_*-subdirs> [kernel-regex]"""
 import collections, csv, glob, re, sys
-pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"(ekf_fuse_kernel|fuse_pipeline_kernel|ekf_wave_kernel<[\w, ]+>|umeyama_batch_kernel|ransac_batch_kernel|utm_kernel<\w+>)")
+pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"(ekf_fuse_kernel|fuse_pipeline_kernel|ekf_wave_kernel<[\w, ]+>|ekf_wave_big_kernel<[\w, ]+>|umeyama_batch_kernel|ransac_batch_kernel|utm_kernel<\w+>)")
 res, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
