@@ -249,7 +249,7 @@ def profiled_stream_rate():
         return None
     try:
         for r in csv.DictReader(open(files[-1])):
-            if r["kernel"] == "apply_sim3_kernel" and int(r["grid_threads"]) == 25600000:       # 1e8 poses, 112 B each
+            if r["kernel"] in ("apply_sim3_slab_kernel", "apply_sim3_kernel") and int(r["grid_threads"]) == 25600000:       # 1e8 poses, 112 B each
                 return 1e8 * 112 / (float(r["avg_us"]) * 1e-6), os.path.basename(files[-1])
     except Exception:
         pass

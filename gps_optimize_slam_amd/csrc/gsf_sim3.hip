@@ -908,6 +908,84 @@ __global__ __launch_bounds__(256) void apply_sim3_kernel(const double* __restric
     if (bad_quat && bad) atomicOr(&bad_quat[b], 1);
 }
 
+// K3 with the rows moved as SLABS (the big-batch EKF kernel's scheme, gsf_wave_common.hpp): a wave takes 64 consecutive poses of a
+// trajectory, fetches their pos / quat slabs (1 536 + 2 048 contiguous bytes) as 16-byte pieces lane after lane, transposes through its own
+// 3.5 KB of LDS so that every lane holds one pose, transforms it, and sends the results back the same way -- four loads and four stores of a
+// kilobyte per 64 poses instead of seven + seven 8-byte accesses at 24 / 32-byte stride.  The next chunk's pieces are requested before the
+// current chunk is transformed.  Same arithmetic per pose as apply_sim3_kernel: same bits.
+typedef double k3_v2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ int k3_piece_off(const int piece, const int slab_bytes) { const int o = piece * 16; return o < slab_bytes - 16 ? o : slab_bytes - 16; }
+__global__ __launch_bounds__(256) void apply_sim3_slab_kernel(const double* __restrict__ pos, const double* __restrict__ quat,
+                                                              const int64_t* __restrict__ offsets, const double* __restrict__ R,
+                                                              const double* __restrict__ t, const double* __restrict__ s,
+                                                              double* __restrict__ pos_out, double* __restrict__ quat_out,
+                                                              int32_t* __restrict__ bad_quat)
+{
+    __shared__ double stage_all[4][64 * 7];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* stage = stage_all[wv];
+    char* sp = (char*)stage; char* sq = sp + 64 * 24;
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = offsets[b], i1 = offsets[b + 1];
+    double Rb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rb[k] = R[b * 9 + k];
+    const double t0 = t[b * 3], t1 = t[b * 3 + 1], t2 = t[b * 3 + 2], sb = s[b];
+    const Quat qR = quat_from_matrix(Rb);                                    // ref :465
+    int bad = 0;
+    const int64_t nchunks = (i1 - i0 + 63) / 64, cstep = 4 * (int64_t)gridDim.y;
+    auto fetch = [&](const int64_t c, k3_v2* P, k3_v2* Q) {
+        const int64_t r0 = i0 + (c < nchunks ? c : nchunks - 1) * 64;        // past the end: any chunk of the track, never used
+        const int rows = (int)(i1 - r0 < 64 ? i1 - r0 : 64);
+        const char* pb = (const char*)(pos + r0 * 3); const char* qb = (const char*)(quat + r0 * 4);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            P[k] = __builtin_nontemporal_load((const k3_v2*)(pb + k3_piece_off(lane + 64 * k, rows * 24)));
+            Q[k] = __builtin_nontemporal_load((const k3_v2*)(qb + k3_piece_off(lane + 64 * k, rows * 32)));
+        }
+    };
+    k3_v2 P[2], Q[2];
+    int64_t c = (int64_t)blockIdx.y * 4 + wv;
+    if (c < nchunks) fetch(c, P, Q);
+    for (; c < nchunks; c += cstep) {
+        const int64_t r0 = i0 + c * 64;
+        const int rows = (int)(i1 - r0 < 64 ? i1 - r0 : 64);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            *(k3_v2*)(sp + k3_piece_off(lane + 64 * k, rows * 24)) = P[k];
+            *(k3_v2*)(sq + k3_piece_off(lane + 64 * k, rows * 32)) = Q[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // a wave's LDS operations complete in order: no barrier between its own phases
+        if (c + cstep < nchunks) fetch(c + cstep, P, Q);                     // (wave-uniform) the next chunk travels while this one is transformed
+        const int r = lane < rows ? lane : rows - 1;
+        const double* dp = (const double*)sp + r * 3; const double* dq = (const double*)sq + r * 4;
+        const double x = dp[0], y = dp[1], z = dp[2];
+        const Quat qin{ dq[0], dq[1], dq[2], dq[3] };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double ox = sb * (x * Rb[0] + y * Rb[1] + z * Rb[2]) + t0;     // ref :464
+        const double oy = sb * (x * Rb[3] + y * Rb[4] + z * Rb[5]) + t1;
+        const double oz = sb * (x * Rb[6] + y * Rb[7] + z * Rb[8]) + t2;
+        Quat qn; const bool ok = quat_unit(qin, qn);
+        Quat o = quat_mul(qR, qn);                                           // ref :466
+        if (!ok) { o = Quat{ NAN, NAN, NAN, NAN }; if (lane < rows) bad = 1; }
+        double* wp = (double*)sp + lane * 3; double* wq = (double*)sq + lane * 4;
+        wp[0] = ox; wp[1] = oy; wp[2] = oz; wq[0] = o.x; wq[1] = o.y; wq[2] = o.z; wq[3] = o.w;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int ppieces = (rows * 3) / 2, qpieces = rows * 2;
+        k3_v2* ps = (k3_v2*)(pos_out + r0 * 3); k3_v2* qs = (k3_v2*)(quat_out + r0 * 4);
+        const k3_v2* svp = (const k3_v2*)sp; const k3_v2* svq = (const k3_v2*)sq;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pc = lane + 64 * k;
+            if (pc < ppieces) __builtin_nontemporal_store(svp[pc], &ps[pc]);
+            if (pc < qpieces) __builtin_nontemporal_store(svq[pc], &qs[pc]);
+        }
+        if ((rows & 1) && lane == 0) __builtin_nontemporal_store(((const double*)sp)[rows * 3 - 1], &pos_out[(r0 + rows) * 3 - 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the pieces are read before the next chunk's land in the stage
+    }
+    if (bad_quat && __ballot(bad != 0) != 0ull && lane == 0) atomicOr(&bad_quat[b], 1);
+}
+
 }  // namespace
 
 namespace gsf {
@@ -1038,7 +1116,10 @@ int gsf_apply_sim3_batch_dev(gsf_ctx* ctx, const double* pos, const double* quat
     if (bad_quat) GSF_HIP(hipMemsetAsync(bad_quat, 0, (size_t)B * 4, ctx->stream));
     // few trajectories -> several blocks per trajectory so a single long track still fills the chip
     const unsigned gy = B >= 2048 ? 1u : (B >= 256 ? 4u : 64u);
-    hipLaunchKernelGGL(apply_sim3_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
+    if (ctx->ekf_variant == 11)                                              // A/B: the per-pose accesses of rounds 1-2
+        hipLaunchKernelGGL(apply_sim3_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
+    else
+        hipLaunchKernelGGL(apply_sim3_slab_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -24,7 +24,7 @@ ROWS = [
     ("bench_default", "fuse_pipeline_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_fuse_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "windows_fused_kernel", 1000064, "C4 1 M windows x 50 pairs (Umeyama)", 1_000_000, 1_000_000 * 2504, "windows"),
-    ("aux", "apply_sim3_kernel", 25600000, "K3 apply Sim3, 1e8 poses", 100_000_000, 100_000_000 * 112, "poses"),
+    ("aux", "apply_sim3_slab_kernel", 25600000, "K3 apply Sim3, 1e8 poses", 100_000_000, 100_000_000 * 112, "poses"),
     ("aux", "utm_kernel<false>", 25600000, "K1 UTM forward, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "utm_kernel<true>", 25600000, "K1 UTM inverse, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "gps_rows_to_utm_kernel", 25600000, "geodesy slice (mask + zone + forward + alt), 1e8 rows", 100_000_000, 100_000_000 * 48, "rows"),
