@@ -124,3 +124,14 @@ def test_spawned_ranks_report_a_stalled_or_failed_rank(monkeypatch):
     assert bench.spawn_ranks(2) == 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os._exit(0)" not in src and "os._exit(STALL_EXIT_CODE)" in src
+
+
+def test_stream_rate_of_the_committed_aux_profile():
+    """roofline.stream of big batches divides the counter bytes by the rate K3 moved the same pose rows at in the committed profile of the
+    auxiliary kernels: the figure must be there and be a plausible HBM rate (between half and all of the 8 TB/s peak)."""
+    import bench
+    got = bench.profiled_stream_rate()
+    assert got is not None, "profiles/rNN_aux_by_kernel_and_grid.csv holds no apply_sim3 row at 1e8 poses"
+    rate, src = got
+    assert 4.0e12 < rate < 8.0e12, rate
+    assert src.endswith("_aux_by_kernel_and_grid.csv")

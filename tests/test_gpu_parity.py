@@ -1229,6 +1229,36 @@ def test_device_mt19937_choice_matches_numpy(B):
     assert np.random.random() == after
 
 
+def test_k3_slab_build_equals_the_per_pose_build(B):
+    """K3 moves its rows as slabs through LDS (apply_sim3_slab_kernel, the default) -- same arithmetic per pose as the per-pose kernel
+    (gsf_set_option "ekf_variant" 11): identical bits on ragged sets with every kind of length (1, odd, 63 / 64 / 65, longer than a
+    block's stride), invalid quaternions included."""
+    import torch
+    rng = np.random.default_rng(4)
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    for trial in range(3):
+        lens = np.array([1, 2, 3, 63, 64, 65, 127, 129, 271, 1000, 1025]) if trial == 0 else rng.integers(1, 500, size=int(rng.integers(1, 200)))
+        offs = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device="cuda")
+        n, nb = int(offs[-1]), len(lens)
+        pos = torch.randn(n, 3, dtype=torch.float64, device="cuda", generator=g) * 100
+        quat = torch.randn(n, 4, dtype=torch.float64, device="cuda", generator=g)
+        quat[rng.integers(0, n, size=max(1, n // 300))] = 0.0
+        A = torch.linalg.qr(torch.randn(nb, 3, 3, dtype=torch.float64, device="cuda", generator=g))[0]
+        R = (A * torch.sign(torch.linalg.det(A)).reshape(nb, 1, 1)).reshape(nb, 9).contiguous()
+        t = torch.randn(nb, 3, dtype=torch.float64, device="cuda", generator=g) * 1e5
+        s_ = torch.rand(nb, dtype=torch.float64, device="cuda", generator=g) + 0.5
+        out = {}
+        try:
+            for var in (0, 11):
+                B.context().set_option("ekf_variant", var)
+                out[var] = [o.cpu().numpy() for o in B.apply_sim3_batch(pos, quat, offs, R, t, s_)]
+        finally:
+            B.context().set_option("ekf_variant", 0)
+        for a, b_ in zip(out[0], out[11]):
+            np.testing.assert_array_equal(a, b_)
+        assert np.isnan(out[0][1]).any()                                 # the invalid quaternions did come out as NaN rows
+
+
 def test_k2b_single_precision_screen_keeps_the_double_counts(B):
     """K2b counts the inliers of every hypothesis with a packed single-precision screen and re-checks in double every row inside the
     rounding band (csrc/gsf_sim3.hip): counts, masks, fits and statuses must be those of the all-double count -- also with rows planted
