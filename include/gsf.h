@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - plain pointers + sizes only; every pointer is caller-owned, the library never
- *     retains or frees it.  All floating point is IEEE float64.  Quaternions are
+ *     retains or frees it.  All floating-point arrays are IEEE float64 and results are those of
+ *     float64 arithmetic (gsf_set_option "k2b_screen" describes the one internal exception).  Quaternions are
  *     scalar-last [x,y,z,w] (SciPy convention, as in the reference's TUM files).
  *   - `*_dev` entry points take DEVICE pointers and are asynchronous on the context's
  *     HIP stream; the matching host-pointer entry points copy in/out and synchronise.
