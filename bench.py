@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- fused poses/sec of the GPS<->SLAM fusion hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--no-cpu-baseline] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--fit-rows reference|all] [--no-cpu-baseline] [--no-extra]
 
 A "step" is one pass of the hot path over one batch of synthetic, HBM-resident trajectories: one launch of the fused
-pipeline kernel (Umeyama fit on the valid rows -> Sim3 of pose 0 -> EKF predict/update + per-outage RTS), i.e. steps
-3-5 of the reference's main_process_gui (EKFGPSSLAM.py:1002-1010) for every trajectory of the batch.
+pipeline kernel (Umeyama fit -> Sim3 of pose 0 -> EKF predict/update + per-outage RTS), i.e. steps 3-5 of the reference's
+main_process_gui (EKFGPSSLAM.py:1002-1010) for every trajectory of the batch.  The rows of the fit are the ones main_process_gui
+hands to its fit (--fit-rows reference, the default: first gap-free segment of the valid rows, <= 180 s, two fall-backs; ref :973-998)
+or every valid row (--fit-rows all, the operator of rounds 1-3); the line reports both.
 Workloads (BASELINE.json configs):
   c2 (default, configs[1]) 1k synthetic KITTI-04-length (271-pose) trajectories per GPU
   c3 (configs[2])          100k synthetic 1k-pose trajectories per GPU (HBM-bound regime)
@@ -114,7 +116,22 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(B_mod, N, target_seconds=8.0):
+def reference_python_timing():
+    """tools/reference_timing.json: the REFERENCE ITSELF (EKFGPSSLAM.py, stubbed import) timed next to the oracle in the build container
+    by tools/time_reference.py -- the reference's files never travel to the GPU box, so this is a committed measurement, quoted."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "tools", "reference_timing.json")))
+        h = d["headline"]
+        return {"reference_python_poses_per_s": h["reference_python_poses_per_s"], "oracle_poses_per_s_same_inputs_same_box": h["oracle_poses_per_s_same_inputs"],
+                "oracle_over_reference": h["oracle_over_reference"], "what": h["what"],
+                "where": f"{d['where']}, {d['cpu']}, {d['cores_used']} core, {d['date']} (tools/time_reference.py; the reference is single-threaded Python)",
+                "steps_2_to_5_reference_poses_per_s": d["cases"]["synthetic_271_with_outage"]["steps_2_to_5"]["reference_poses_per_s"],
+                "robust_fit_reference_ms": d["cases"]["synthetic_271_with_outage"]["compute_sim3_transform_robust"]["reference_ms"]}
+    except Exception as e:
+        return {"error": f"tools/reference_timing.json unreadable: {e}"[:200]}
+
+
+def cpu_baseline(B_mod, N, target_seconds=8.0, fit_rows="reference"):
     """The oracle (dense-7x7 C restatement of the reference path) on a bounded sample of the same synthetic workload: (i) ONE
     thread -- like for like with the single-threaded reference -- and (ii) trajectory-parallel over every host core (threads:
     ctypes releases the GIL and the C code has no shared state)."""
@@ -132,7 +149,7 @@ def cpu_baseline(B_mod, N, target_seconds=8.0):
 
     def run(h):                                    # the same step as the GPU: Umeyama(valid rows) -> Sim3(pose 0) -> EKF+RTS
         t0 = time.perf_counter()
-        orc.fuse_pipeline_batch(h["ts"], h["pos"], h["quat"], h["gps"], h["valid"])
+        orc.fuse_pipeline_batch(h["ts"], h["pos"], h["quat"], h["gps"], h["valid"], fit_rows=fit_rows)
         return time.perf_counter() - t0
 
     h = sample(256, 99)
@@ -155,7 +172,7 @@ def cpu_baseline(B_mod, N, target_seconds=8.0):
     def worker(_):
         n = 0
         while True:                                # at least one repetition, then until the shared deadline
-            orc.fuse_pipeline_batch(hw["ts"], hw["pos"], hw["quat"], hw["gps"], hw["valid"])
+            orc.fuse_pipeline_batch(hw["ts"], hw["pos"], hw["quat"], hw["gps"], hw["valid"], fit_rows=fit_rows)
             n += 1
             if time.perf_counter() >= t_end[0]:
                 return n
@@ -167,6 +184,10 @@ def cpu_baseline(B_mod, N, target_seconds=8.0):
     dta = time.perf_counter() - t0
     res["all_cores"] = {"value": done * nbw * N / dta, "unit": "fused poses/s", "cores": cores,
                         "sample": f"{cores} threads (every core usable by this process) fused {done} blocks of {nbw} trajectories x {N} poses in {dta:.1f} s"}
+    # the port is a C restatement; the reference it restates is single-threaded Python, two orders of magnitude slower (measured in the
+    # build container, where the reference can be imported)
+    res["reference_python"] = reference_python_timing()
+    res["fit_rows"] = fit_rows
     return res
 
 
@@ -263,7 +284,7 @@ STALL_EXIT_CODE = 3                # a rank whose collect leg stalled has printe
 
 
 def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N, passes=1, stall_cb=None, stall_seconds=240.0,
-           leg_budget_s=150.0, inject_stall_s=0.0):
+           leg_budget_s=150.0, inject_stall_s=0.0, fit_rows="reference"):
     import ctypes as C
     import threading
 
@@ -286,6 +307,8 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
     s_comp, s_comm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     with torch.cuda.stream(s_comp):
         ctx = B.context()
+        ctx.set_sim3_rows(fit_rows, B.CONFIG)
+        info["fit_rows"] = fit_rows
         batch = B.TrajectoryBatch(B.LAYOUT_TRAJ_MAJOR, T, N, dev)
         t0 = time.perf_counter()
         for lo in range(0, T, 65536):                                      # generated in place, this rank's ids
@@ -434,6 +457,35 @@ def run_c5(torch, B, D, rank, world, dev, rehearsal, traj_per_gpu, chunk_traj, N
     return info
 
 
+def spread_sample(n_traj, n=64):
+    """indices of a sample spread over a batch: its first, middle and last wave-sized slices (the gate must not look at the head only)"""
+    import numpy as np
+    if n_traj <= n:
+        return np.arange(n_traj)
+    a, b = n // 3, n // 3
+    c = n - a - b
+    mid = n_traj // 2
+    return np.unique(np.concatenate([np.arange(a), np.arange(mid - b // 2, mid - b // 2 + b), np.arange(n_traj - c, n_traj)]))
+
+
+def oracle_gate(np, torch, B, bt, pos_out, status, idx, fit_rows, R=None):
+    """The TIMED outputs of trajectories `idx` of a trajectory-major batch against oracle.fuse_pipeline_batch under the same row rule:
+    ATE RMSE, max |dp|, status words (the informational SVD-fallback bit aside)."""
+    from oracle import oracle as orc
+    ix = torch.as_tensor(idx, device=bt.ts.device)
+    hh = {k: getattr(bt, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid")}
+    po, qo, sto, Ro, _, _ = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], fit_rows=fit_rows)
+    pg, sg = pos_out.index_select(0, ix).cpu().numpy(), status.index_select(0, ix).cpu().numpy()
+    fin = np.isfinite(po).all(axis=(1, 2))
+    res = {"sample": f"{len(idx)} trajectories spread over the batch (first / middle / last slice)", "fit_rows": fit_rows,
+           "ate_rmse_vs_cpu_ref_m": float(np.sqrt(np.mean(np.sum((pg[fin] - po[fin]) ** 2, axis=2)))) if fin.any() else None,
+           "max_abs_pos_err_m": float(np.abs(pg[fin] - po[fin]).max()) if fin.any() else None,
+           "status_words_equal": bool(((sg & ~(16 << 8)) == sto).all()) and bool((np.isfinite(pg).all(axis=(1, 2)) == fin).all())}
+    if R is not None:
+        res["max_abs_sim3_R_err"] = float(np.nanmax(np.abs(R.index_select(0, ix).cpu().numpy() - Ro)))
+    return res
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def worker(args):
     import numpy as np
@@ -475,10 +527,18 @@ def worker(args):
     for kv in args.set_option:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
+    ctx.set_sim3_rows(args.fit_rows, B.CONFIG)                             # rows of the pipeline's fit on every raw launch below
     L = _lib.load()
     base = {"metric": "fused poses/sec (whole node)", "unit": "fused poses/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "backend": backend if world > 1 else "single process (no collective)", "gpus_visible": ngpu}
+    # which build of the library this is: scheduler / -ffp-contract mode / compiler of every wave-level translation unit (gsf_version()),
+    # and the Makefile's warning file if a translation unit took its fall-back path
+    warn_path = os.path.join(ROOT, "gps_optimize_slam_amd", "BUILD_WARNINGS.txt")
+    base["build"] = {"gsf_version": L.gsf_version().decode(), "library": os.path.basename(_lib.library_path()),
+                     "build_warnings": open(warn_path).read().strip() if os.path.exists(warn_path) else None}
+    if base["build"]["build_warnings"] and rank == 0:
+        print("bench.py: BUILD WARNING -- " + base["build"]["build_warnings"], file=sys.stderr)
     partial = {}                                   # what rank 0 prints if the run-wide deadline fires (N > 1 only)
     if world > 1:
         import threading
@@ -513,7 +573,7 @@ def worker(args):
                           c5=info)
             print(json.dumps(result), flush=True)
         info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps), stall_cb=emit_c5,
-                      stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall)
+                      stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
         emit_c5(info)
         if world > 1:
             run_deadline.cancel()
@@ -559,6 +619,7 @@ def worker(args):
                 for kv in args.set_option:
                     k_, v_ = kv.split("=")
                     B.context().set_option(k_, int(v_))
+                B.context().set_sim3_rows(args.fit_rows, B.CONFIG)
                 launch(hc)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -675,17 +736,22 @@ def worker(args):
                              "gathered_blocks_equal_rank_checksums": bool(torch.equal(blocks, allsums)),
                              "backend": torch.distributed.get_backend()}
     partial.update(result)
-    # ---- accuracy gate on THIS run: the timed `out` buffers (a sample of the timed batch) against the CPU oracle on the same inputs
+    # ---- accuracy gate on THIS run: the timed `out` buffers (a sample SPREAD over the timed batch) against the CPU oracle on the same inputs
     if rank == 0:
         from oracle import oracle as orc
-        nb = min(Bn, 64)
+        idx = spread_sample(Bn, 64)
+        nb = len(idx)
         torch.cuda.synchronize()
-        hh = {k: getattr(batch, k)[:nb].cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
-        pg, qg, sg = out.pos[:nb].cpu().numpy(), out.quat[:nb].cpu().numpy(), out.status[:nb].cpu().numpy()
+        ix = torch.as_tensor(idx, device=dev)
+        hh = {k: getattr(batch, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
+        pg, qg, sg = out.pos.index_select(0, ix).cpu().numpy(), out.quat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
+        result["gate_sample"] = f"{nb} trajectories of the timed batch: ids {int(idx[0])}..{int(idx[nb // 3 - 1])}, {int(idx[nb // 3])}..{int(idx[2 * (nb // 3) - 1])}, {int(idx[2 * (nb // 3)])}..{int(idx[-1])}"
         if args.kernel == "pipeline":
-            po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"])
-            result["gated"] = "timed fused-pipeline outputs (Umeyama -> Sim3 of pose 0 -> EKF+RTS) vs oracle.fuse_pipeline_batch"
-            result["max_abs_sim3_R_err"] = float(np.abs(R[:nb].cpu().numpy() - Ro).max())
+            po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], fit_rows=args.fit_rows)
+            rows_txt = ("the rows main_process_gui hands to its fit, EKFGPSSLAM.py:973-998" if args.fit_rows == "reference" else "every row with valid finite GNSS")
+            result["gated"] = f"timed fused-pipeline outputs (Umeyama on {rows_txt} -> Sim3 of pose 0 -> EKF+RTS) vs oracle.fuse_pipeline_batch(fit_rows='{args.fit_rows}')"
+            result["max_abs_sim3_R_err"] = float(np.nanmax(np.abs(R.index_select(0, ix).cpu().numpy() - Ro)))
+            result["fit_status_words_equal"] = bool((((sg >> 8) & ~16) == (sto >> 8)).all())
         else:
             po, qo, sto = orc.fuse_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], hh["init_pos"], hh["init_quat"])
             result["gated"] = "timed K4 outputs vs oracle.fuse_batch"
@@ -695,13 +761,44 @@ def worker(args):
         result["max_abs_quat_err"] = float(np.abs(qg[fin] - qo[fin]).max())
         result["status_bits_equal"] = bool(((sg & 0xff) == (sto & 0xff)).all()) and bool((np.isfinite(pg).all(axis=(1, 2)) == fin).all())
         # the reference's own error metric (Q15, EKFGPSSLAM.py:1013-1033) of both results against the synthetic GNSS
-        stats, _ = B.eval_errors_batch(batch.ts[:nb], out.pos[:nb].contiguous(), batch.gps[:nb], batch.valid[:nb], 5.0)
+        stats, _ = B.eval_errors_batch(batch.ts.index_select(0, ix), out.pos.index_select(0, ix).contiguous(), batch.gps.index_select(0, ix),
+                                       batch.valid.index_select(0, ix), 5.0)
         g_rmse = stats[:, 3].cpu().numpy()
         c_rmse = np.array([orc.evaluate_trajectory_errors(hh["ts"][b], po[b], hh["gps"][b], hh["valid"][b])["rmse"] for b in range(nb)])
         both = np.isfinite(g_rmse) & np.isfinite(c_rmse)
         result["ref_style_error_q15"] = {"gpu_rmse_m_mean": float(g_rmse[both].mean()), "cpu_rmse_m_mean": float(c_rmse[both].mean()),
                                          "max_abs_diff_m": float(np.abs(g_rmse[both] - c_rmse[both]).max()), "trajectories": int(both.sum()),
                                          "definition": "min distance to any candidate fix after the first 5 s, RMSE per trajectory (EKFGPSSLAM.py:1013-1033)"}
+    # ---- both definitions of the fit's rows in one line: the headline above is --fit-rows; here the other one, same batch, same box
+    if args.kernel == "pipeline":
+        other = "all" if args.fit_rows == "reference" else "reference"
+        torch.cuda.synchronize()
+        st_head = out.status.clone(); R_head = R.clone()
+        ctx.set_sim3_rows(other, B.CONFIG)
+        k3 = max(20, min(steps, 500))
+        for _ in range(10):
+            launch()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ea.record()
+        for _ in range(k3):
+            launch()
+        eb.record(); torch.cuda.synchronize()
+        ms_other = ea.elapsed_time(eb) / k3
+        changed = int((R_head - R).abs().amax(dim=1).gt(0).sum().item())
+        rows_bits = (st_head >> 8) if args.fit_rows == "reference" else (out.status >> 8)
+        result["fit_rows"] = {"headline": args.fit_rows,
+                              "definitions": {"reference": "the rows main_process_gui hands to its fit (EKFGPSSLAM.py:973-998): first gap-free segment of the valid rows, "
+                                                           "<= max_initial_duration, fall-backs :984-986 / :993-995",
+                                              "all": "every row with valid finite GNSS (the operator SURVEY 8(b)/(d) defined; rounds 1-3)"},
+                              "other": {"fit_rows": other, "kernel_ms": ms_other, "value": world * Bn * N / (ms_other * 1e-3), "launch_mode": f"{k3} eager launches",
+                                        "hbm_frac": alg_bytes / (ms_other * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              "tracks_whose_fit_differs_between_the_two": changed, "tracks": Bn,
+                              "reference_rule_branches": {"first_segment_too_short_all_rows": int(((rows_bits & 64) != 0).sum().item()),
+                                                          "duration_limit_dropped_whole_segment": int(((rows_bits & 128) != 0).sum().item()),
+                                                          "too_few_rows_value_error": int(((rows_bits & 32) != 0).sum().item())}}
+        ctx.set_sim3_rows(args.fit_rows, B.CONFIG)
+        launch(); torch.cuda.synchronize()                                 # leave the headline definition's outputs in `out` for the extras
     # ---- extras (rank 0, N=1): PCIe-inclusive rate, the HBM-regime config, the drop-in's single-run latency
     if world == 1 and not args.no_extra:
         result["extra"] = extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args)
@@ -717,12 +814,12 @@ def worker(args):
                 print(json.dumps(result), flush=True)
         try:
             info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5,
-                          stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall)
+                          stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
         except Exception as e:                  # sizes are symmetric over ranks, so a failure (e.g. out of memory) is too
             info = {"error": f"{type(e).__name__}: {e}"[:300]}
         result["c5"] = info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(B, N)
+        result["cpu_baseline"] = cpu_baseline(B, N, fit_rows=args.fit_rows)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -770,8 +867,20 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
                 bt = B.TrajectoryBatch.synthetic(b3, n3, layout=lay, seed=1)
                 o = B.FusedPoses(bt.layout, b3, n3, dev)
                 ms_e = timed(lambda: B.ekf_fuse_batch(bt, out=o), reps)
-                ms_p = timed(lambda: B.fuse_pipeline_batch(bt, out=o), reps)
-                extra[name][lname] = {"ekf_kernel_ms": ms_e, "ekf_poses_per_s": b3 * n3 / ms_e * 1e3, "ekf_alg_GBps": ab / ms_e / 1e6,
+                Rk = [None]
+
+                def pipe():
+                    Rk[0] = B.fuse_pipeline_batch(bt, out=o, fit_rows=args.fit_rows)[1]
+                ms_p = timed(pipe, reps)
+                ms_pa = timed(lambda: B.fuse_pipeline_batch(bt, out=o, fit_rows="all" if args.fit_rows == "reference" else "reference"), reps)
+                gate = None
+                if lay == B.LAYOUT_TRAJ_MAJOR:                              # the timed outputs of the headline definition, a sample spread over the batch
+                    pipe(); torch.cuda.synchronize()
+                    try:
+                        gate = oracle_gate(np, torch, B, bt, o.pos, o.status, spread_sample(b3, 64), args.fit_rows, Rk[0])
+                    except Exception as e:
+                        gate = {"error": f"{type(e).__name__}: {e}"[:200]}
+                extra[name][lname] = {"fit_rows": args.fit_rows, "pipeline_kernel_ms_other_fit_rows": ms_pa, "gate_vs_oracle": gate,"ekf_kernel_ms": ms_e, "ekf_poses_per_s": b3 * n3 / ms_e * 1e3, "ekf_alg_GBps": ab / ms_e / 1e6,
                                       "ekf_hbm_frac": ab / ms_e / 1e6 / HBM_PEAK_GBS, "pipeline_kernel_ms": ms_p,
                                       "pipeline_poses_per_s": b3 * n3 / ms_p * 1e3, "pipeline_alg_GBps": ab / ms_p / 1e6,
                                       "pipeline_hbm_frac": ab / ms_p / 1e6 / HBM_PEAK_GBS,
@@ -791,19 +900,69 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         extra["geodetic_chain_c2"] = {"ms": ms_g, "poses_per_s": 271e3 / ms_g * 1e3, "gnss_fixes": int(gb.gps_t.numel()),
                                       "stages": "gsf_gps_rows_to_utm_batch_dev -> gsf_time_align_batch_dev -> gsf_fuse_pipeline_batch_dev"}
         del gb, og
-        bt = B.TrajectoryBatch.synthetic(1000, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
-        o = B.FusedPoses(bt.layout, 1000, 271, dev)
-        st0 = B.mt19937_seed(np.arange(1000))
-        ms_r = timed(lambda: B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False), 5)
-        extra["robust_chain_c2"] = {"ms": ms_r, "poses_per_s": 271e3 / ms_r * 1e3, "max_trials": B.CONFIG["sim3_ransac"]["max_trials"],
-                                    "stages": "compact -> mt19937 choice (1000 x permutation(n)[:4] per trajectory) -> K2b -> Sim3(pose 0) -> K4"}
-        del bt, o, st0
+        extra["robust_chain_c2"] = robust_chain(torch, np, B, timed, dev, 1000, 271, args.fit_rows, parity=32)
+        extra["robust_chain_8192"] = robust_chain(torch, np, B, timed, dev, 8192, 271, args.fit_rows, parity=0)
+        a_, b_ = extra["robust_chain_c2"], extra["robust_chain_8192"]
+        if "ms" in a_ and "ms" in b_:
+            b_["per_stream_cost_vs_1000_streams"] = (b_["ms"] / 8192) / (a_["ms"] / 1000)
+            b_["draws_per_stream_cost_vs_1000_streams"] = (b_["draws_ms"] / 8192) / (a_["draws_ms"] / 1000)
         extra["c1_drop_in"] = c1_latency(np)
         extra["fit_distributions_c2"] = fit_distributions(torch, np, B, timed, dev)
         extra["c4_1M_x_50"] = c4_windows(torch, B, timed)
         torch.cuda.empty_cache()
-        extra["c5_shard_1gpu"] = c5_shard(torch, B, L, dev, timed)
+        extra["c5_shard_1gpu"] = c5_shard(torch, B, L, dev, timed, fit_rows=args.fit_rows)
     return extra
+
+
+def robust_chain(torch, np, B, timed, dev, nb, N, fit_rows, parity=0):
+    """Steps 3-5 with the reference's ROBUST fit as one device chain at `nb` streams (EKFGPSSLAM.py:1002-1010, :389-426): wall time of the
+    chain and of its draws alone; with parity > 0 a sample of the TIMED run against the oracle fed with NumPy's own draws for the same seeds."""
+    from oracle import oracle as orc
+    try:
+        bt = B.TrajectoryBatch.synthetic(nb, N, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
+        o = B.FusedPoses(bt.layout, nb, N, dev)
+        st0 = B.mt19937_seed(np.arange(nb))
+        sc = B.CONFIG["sim3_ransac"]
+        keep = [None]
+
+        def chain():
+            keep[0] = B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False, fit_rows=fit_rows)
+        ms_r = timed(chain, 5)
+        npop = torch.full((nb,), N, dtype=torch.int32, device=dev)
+        ms_d = timed(lambda: B.mt19937_choice_batch(st0.clone(), npop, sc["max_trials"], sc["min_samples"]), 5)
+        res = {"ms": ms_r, "poses_per_s": nb * N / ms_r * 1e3, "streams": nb, "max_trials": sc["max_trials"], "fit_rows": fit_rows,
+               "ms_per_1000_streams": ms_r / nb * 1000, "draws_ms": ms_d, "draws_us_per_trial_step": ms_d * 1e3 / sc["max_trials"],
+               "draws_ns_per_stream_trial": ms_d * 1e6 / (nb * sc["max_trials"]),
+               "stages": "row choice -> compact -> mt19937 choice (1000 x permutation(n)[:4] per trajectory) -> K2b -> Sim3(pose 0) -> K4"}
+        if parity > 0:
+            chain(); torch.cuda.synchronize()
+            out, R, t, s, nin, _ = keep[0]
+            idx = spread_sample(nb, parity)
+            ix = torch.as_tensor(idx, device=dev)
+            hh = {k_: getattr(bt, k_).index_select(0, ix).cpu().numpy() for k_ in ("ts", "pos", "quat", "gps", "valid")}
+            pg, sg = out.pos.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
+            Rg, ng = R.index_select(0, ix).cpu().numpy(), nin.index_select(0, ix).cpu().numpy()
+            ta, tg = B.CONFIG["time_alignment"], B.CONFIG["sim3_ransac"]
+            worst, rworst, ok_status, ok_count = 0.0, 0.0, True, True
+            for k_, b_ in enumerate(idx):
+                okr = (hh["valid"][k_] != 0) & ~np.isnan(hh["gps"][k_]).any(axis=1)
+                rows = np.where(okr)[0] if fit_rows == "all" else orc.pick_sim3_rows(hh["ts"][k_], okr, tg["min_samples"], ta["max_gps_gap_threshold"], tg["max_initial_duration"])
+                np.random.seed(int(b_))
+                draws = np.stack([np.random.choice(len(rows), sc["min_samples"], replace=False) for _ in range(sc["max_trials"])]).astype(np.int32)
+                Ro, to, so, mo = orc.compute_sim3_transform_robust(hh["pos"][k_][rows], hh["gps"][k_][rows], sc["min_samples"], sc["residual_threshold"], sc["max_trials"],
+                                                                   sc["min_inliers_needed"], sample_idx=draws, return_mask=True)
+                sp, sq = orc.transform_trajectory(hh["pos"][k_][:1], hh["quat"][k_][:1], Ro, to, so)
+                po, qo, sto = orc.apply_ekf_correction_aligned(hh["ts"][k_], hh["pos"][k_], hh["quat"][k_], hh["gps"][k_], hh["valid"][k_], sp[0], sq[0], return_status=True)
+                worst = max(worst, float(np.abs(pg[k_] - po).max())); rworst = max(rworst, float(np.abs(Rg[k_].reshape(3, 3) - Ro).max()))
+                ok_status &= bool((sg[k_] & 0xff) == sto); ok_count &= bool(ng[k_] == mo.sum())
+            res["parity_sample_vs_oracle"] = {"trajectories": int(len(idx)), "of_the_timed_run": True, "max_abs_pos_err_m": worst, "max_abs_sim3_R_err": rworst,
+                                              "status_bits_equal": ok_status, "inlier_counts_equal": ok_count,
+                                              "how": "oracle.compute_sim3_transform_robust fed np.random.choice draws of np.random.seed(trajectory id), rows by the same rule"}
+        del bt, o, st0
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def fit_distributions(torch, np, B, timed, dev, nb=1000, N=271):
@@ -879,7 +1038,7 @@ def c4_windows(torch, B, timed, nw=1_000_000, W=50):
     return res
 
 
-def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768):
+def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768, fit_rows="reference"):
     """BASELINE configs[4] on ONE GPU: the per-GPU shard of 10M x 1k trajectories over 8 GPUs (1 245 184 = 38 chunks of 32 768, sized
     down symmetrically to what is free), compute-only pass of the fused pipeline, in BOTH layouts: trajectory-major (wave per trajectory,
     chunk by chunk as the 8-GPU run does) and time-major (lane per trajectory, the whole shard in one launch)."""
@@ -893,7 +1052,10 @@ def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768):
     if T <= 0:
         res["error"] = "not enough free memory for one chunk"
         return res
+    import numpy as np
     ctx = B.context()
+    ctx.set_sim3_rows(fit_rows, B.CONFIG)
+    res["fit_rows"] = fit_rows
     cfg = _lib.EkfConfig.from_config(B.CONFIG)
     f = dict(dtype=torch.float64, device=dev)
     alg = T * N * ALG_BYTES_PER_POSE
@@ -928,6 +1090,25 @@ def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768):
                           "launches_per_pass": T // chunk if lay == B.LAYOUT_TRAJ_MAJOR else 1,
                           "fit_none": int((status >> 8).eq(1).sum().item()), "had_outage": int((status & 1).ne(0).sum().item()),
                           "rts_applied": int((status & 2).ne(0).sum().item()), "sharp_turn": int((status & 4).ne(0).sum().item())}
+            if lay == B.LAYOUT_TRAJ_MAJOR:
+                # the timed outputs against the oracle: 64 trajectories from the first, a middle and the last chunk of the pass
+                try:
+                    nck = T // chunk
+                    gates = []
+                    for k in sorted({0, nck // 2, nck - 1}):
+                        lo = k * chunk
+                        view = B.TrajectoryBatch.__new__(B.TrajectoryBatch)
+                        for nm in ("ts", "pos", "quat", "gps", "valid"):
+                            setattr(view, nm, getattr(bt, nm)[lo:lo + chunk])
+                        pos_k = out[k * P * 7:k * P * 7 + P * 3].view(chunk, N, 3)
+                        gates.append(oracle_gate(np, torch, B, view, pos_k, status[lo:lo + chunk], spread_sample(chunk, 22), fit_rows, R[lo:lo + chunk]))
+                    res[lname]["gate_vs_oracle"] = {"chunks": sorted({0, nck // 2, nck - 1}), "trajectories": sum(int(g["sample"].split()[0]) for g in gates), "fit_rows": fit_rows,
+                                                    "ate_rmse_vs_cpu_ref_m": float(np.sqrt(np.mean([g["ate_rmse_vs_cpu_ref_m"] ** 2 for g in gates]))),
+                                                    "max_abs_pos_err_m": max(g["max_abs_pos_err_m"] for g in gates),
+                                                    "max_abs_sim3_R_err": max(g["max_abs_sim3_R_err"] for g in gates),
+                                                    "status_words_equal": all(g["status_words_equal"] for g in gates)}
+                except Exception as e:
+                    res[lname]["gate_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             del bt, out, R, t, s, status
         except Exception as e:                                             # e.g. out of memory on a smaller card: reported, not fatal
             res[lname] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -938,11 +1119,15 @@ def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768):
 
 
 def c1_latency(np):
-    """Wall time of the drop-in's single-trajectory functions at the C1 shape (271 poses, KITTI-04-like synthetic track; the bundled
-    files stay in the reference tree): steps 2-5 of main_process_gui (EKFGPSSLAM.py:971-1010) next to BASELINE.md's ~0.11 s."""
+    """Wall time of the drop-in's single-trajectory functions at the C1 shape (BASELINE configs[0]): the 271-pose KITTI-04 track and its
+    279 raw GNSS fixes from the committed fixtures tests/golden/{kat_bundled,c1_combined}.npz (data only; the package itself reads no
+    test file): steps 2-5 of main_process_gui (EKFGPSSLAM.py:971-1010) next to the reference's ~0.11 s."""
     from gps_optimize_slam_amd import ekfgpsslam as E
     try:
-        return E.benchmark_c1(repeats=20)
+        gold = os.path.join(ROOT, "tests", "golden")
+        k, g = np.load(os.path.join(gold, "kat_bundled.npz")), np.load(os.path.join(gold, "c1_combined.npz"))
+        slam = {"timestamps": k["ts"], "positions": k["pos"], "quaternions": k["quat"]}
+        return E.benchmark_c1(slam, g["gps_t_raw"], g["lat"], g["lon"], g["alt"], repeats=20)
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 
@@ -954,6 +1139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--kernel", choices=["pipeline", "ekf"], default="pipeline", help="step = fused pipeline (default) or K4 only")
+    ap.add_argument("--fit-rows", choices=["reference", "all"], default="reference",
+                    help="rows of the pipeline's Sim3 fit: what main_process_gui picks (EKFGPSSLAM.py:973-998, default) or every valid row")
     ap.add_argument("--traj-per-gpu", type=int, default=None, help="override the workload's trajectories per GPU (c5: default 1 250 000, sized down to what fits)")
     ap.add_argument("--chunk-traj", type=int, default=None, help="c5: trajectories per chunk (default 32 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -13,6 +13,7 @@ LAYOUT_TRAJ_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
 
 SIM3_NONE = 1
+SIM3_FLAG_FEW_ROWS, SIM3_FLAG_ROWS_ALL, SIM3_FLAG_ROWS_SEGMENT = 32, 64, 128      # row choice of the fused chains (gsf_set_sim3_rows mode 1)
 ST_HAD_OUTAGE, ST_RTS_APPLIED, ST_SHARP_TURN, ST_ENDED_IN_OUTAGE, ST_BAD_QUAT = 1, 2, 4, 8, 16
 
 
@@ -63,7 +64,11 @@ SIGNATURES = {
     "gsf_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "gsf_destroy": (None, [_vp]),
     "gsf_synchronize": (C.c_int, [_vp]),
+    "gsf_trim": (C.c_int, [_vp]),
     "gsf_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "gsf_set_sim3_rows": (C.c_int, [_vp, _i32, _i32, _f64, _f64]),
+    "gsf_sim3_fit_rows_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "gsf_sim3_fit_rows_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
     "gsf_timer_start": (C.c_int, [_vp]),
     "gsf_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "gsf_utm_zone_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -196,6 +201,11 @@ class Context:
         else:
             check(L.gsf_create_on_stream(int(device), _vp(int(stream)), C.byref(h)))
         self._h, self.device, self._L = h, int(device), L
+        self.options = {}
+        # kernel-choice override for A/B runs of the whole test suite (the library itself reads no environment variable)
+        v = os.environ.get("GSF_BLOCK_KERNEL")
+        if v is not None and v.strip() in ("-1", "0", "1"):
+            self.set_option("block_kernel", int(v))
 
     @property
     def handle(self):
@@ -206,6 +216,22 @@ class Context:
 
     def set_option(self, key, value):
         check(self._L.gsf_set_option(self._h, key.encode(), int(value)))
+        self.options[key] = int(value)
+
+    def trim(self):
+        """release the context's grow-only workspaces (gsf_trim)"""
+        check(self._L.gsf_trim(self._h))
+
+    def set_sim3_rows(self, fit_rows, global_config=None):
+        """Which rows feed the Sim3 fit of the fused chains on this context: "reference" (main_process_gui's choice, EKFGPSSLAM.py:973-998,
+        with min_samples / max_gps_gap_threshold / max_initial_duration from the CONFIG dict) or "all" (every valid row)."""
+        if fit_rows in ("all", 0, False, None):
+            check(self._L.gsf_set_sim3_rows(self._h, 0, 0, 0.0, 0.0))
+        elif fit_rows in ("reference", 1, True):
+            r, t = global_config["sim3_ransac"], global_config["time_alignment"]
+            check(self._L.gsf_set_sim3_rows(self._h, 1, int(r["min_samples"]), float(t["max_gps_gap_threshold"]), float(r["max_initial_duration"])))
+        else:
+            raise ValueError(f"fit_rows must be 'reference' or 'all', got {fit_rows!r}")
 
     def timer_start(self):
         check(self._L.gsf_timer_start(self._h))

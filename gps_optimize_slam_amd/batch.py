@@ -62,12 +62,13 @@ class TrajectoryBatch:
         sharp-turn burst on 5 % of the tracks."""
         b = cls(layout, B, N, device)
         ctx = context()
+        previous = ctx.options.get("synth_variant", 0)
         ctx.set_option("synth_variant", int(variant))
         try:
             check(_lib.load().gsf_synth_batch_dev(ctx.handle, b.layout, C.c_uint64(seed), int(traj0), b.B, b.N, _p(b.ts), _p(b.pos),
                                                   _p(b.quat), _p(b.gps), _p(b.valid), _p(b.init_pos), _p(b.init_quat)))
         finally:
-            ctx.set_option("synth_variant", 0)
+            ctx.set_option("synth_variant", previous)
         return b
 
     @classmethod
@@ -140,12 +141,16 @@ class GeodeticBatch:
         return cls(B, N, ts, pos, quat, offs, gps_t, gps_llh, mx)
 
 
-def fuse_from_geodetic(gb, config=None, out=None):
+FIT_ROWS_DEFAULT = "reference"
+
+
+def fuse_from_geodetic(gb, config=None, out=None, fit_rows=FIT_ROWS_DEFAULT):
     """The whole path from the geodetic GNSS log on the device, no host round trip: geodesy slice (mask, zone pick, UTM forward,
-    [E, N, alt] rows; ref :258-271) -> dynamic_time_alignment to the SLAM stamps (ref :325-387, :971) -> Umeyama on the valid rows
-    -> Sim3 of pose 0 -> EKF+RTS (ref :1002-1010, plain fit).  Returns (FusedPoses, R, t, s, aux) with aux = dict(zone, south,
-    utm_rows, aligned, valid)."""
+    [E, N, alt] rows; ref :258-271) -> dynamic_time_alignment to the SLAM stamps (ref :325-387, :971) -> Umeyama on the rows
+    main_process_gui picks (ref :973-998; fit_rows="all": on every valid row) -> Sim3 of pose 0 -> EKF+RTS (ref :1002-1010, plain
+    fit).  Returns (FusedPoses, R, t, s, aux) with aux = dict(zone, south, utm_rows, aligned, valid)."""
     g = config or CONFIG
+    context().set_sim3_rows(fit_rows, g)
     cfg = EkfConfig.from_config(g)
     L, h, dev = _lib.load(), context().handle, gb.ts.device
     f = dict(dtype=torch.float64, device=dev)
@@ -207,10 +212,13 @@ def ekf_fuse_batch(batch, config=None, out=None):
     return out
 
 
-def fuse_pipeline_batch(batch, config=None, out=None):
-    """Umeyama (valid rows) -> Sim3 of pose 0 -> EKF+RTS in one launch (steps 3-5 of EKFGPSSLAM.py:1002-1010, plain fit).
-    Returns (FusedPoses, R (B,9), t (B,3), s (B,))."""
+def fuse_pipeline_batch(batch, config=None, out=None, fit_rows=FIT_ROWS_DEFAULT):
+    """Umeyama -> Sim3 of pose 0 -> EKF+RTS in one launch (steps 3-5 of EKFGPSSLAM.py:1002-1010, plain fit).  fit_rows="reference":
+    the fit sees the rows main_process_gui hands to its fit (first gap-free segment of the valid rows, <= max_initial_duration, two
+    fall-backs; ref :973-998); "all": every row with valid finite GNSS.  status >> 8 carries the GSF_SIM3_* bits (FEW_ROWS = the
+    reference's ValueError).  Returns (FusedPoses, R (B,9), t (B,3), s (B,))."""
     cfg = EkfConfig.from_config(config or CONFIG)
+    context().set_sim3_rows(fit_rows, config or CONFIG)
     out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
     f = dict(dtype=torch.float64, device=batch.ts.device)
     R, t, s = torch.empty((batch.B, 9), **f), torch.empty((batch.B, 3), **f), torch.empty((batch.B,), **f)
@@ -249,13 +257,15 @@ def mt19937_choice_batch(state, n_population, trials, k):
     return idx
 
 
-def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask=True):
-    """Steps 3-5 of main_process_gui with the reference's robust fit (EKFGPSSLAM.py:1002-1010): RANSAC hypotheses drawn on the
-    device from each trajectory's legacy MT19937 stream -> inlier refit -> Sim3 of pose 0 -> EKF+RTS, one chain on torch's current
-    stream.  Trajectory-major batches.  Returns (FusedPoses, R, t, s, n_inliers (B,), inlier_mask (B, N) uint8 or None)."""
+def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask=True, fit_rows=FIT_ROWS_DEFAULT):
+    """Steps 3-5 of main_process_gui with the reference's robust fit (EKFGPSSLAM.py:1002-1010): the rows main_process_gui picks
+    (ref :973-998; fit_rows="all": every valid row) -> RANSAC hypotheses drawn on the device from each trajectory's legacy MT19937
+    stream -> inlier refit -> Sim3 of pose 0 -> EKF+RTS, one chain on torch's current stream.  Trajectory-major batches.  Returns
+    (FusedPoses, R, t, s, n_inliers (B,), inlier_mask (B, N) uint8 or None)."""
     if batch.layout != LAYOUT_TRAJ_MAJOR:
         raise ValueError("fuse_pipeline_robust_batch: trajectory-major batches only")
     g = config or CONFIG
+    context().set_sim3_rows(fit_rows, g)
     cfg, r = EkfConfig.from_config(g), g["sim3_ransac"]
     out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
     f = dict(dtype=torch.float64, device=batch.ts.device)
@@ -267,6 +277,21 @@ def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask
                                                          int(r["max_trials"]), int(r["min_inliers_needed"]), _p(mt_state), _p(R), _p(t), _p(s),
                                                          _p(out.pos), _p(out.quat), _p(out.status), _p(nin), _p(mask)))
     return out, R, t, s, nin, mask
+
+
+def sim3_fit_rows_batch(ts, gps, valid, config=None, offsets=None):
+    """main_process_gui's choice of the rows that feed the global Sim3 (EKFGPSSLAM.py:973-998) for B trajectories on the device: ts (B,N),
+    gps (B,N,3) or None, valid (B,N) uint8 -- or flat tensors with int64 offsets (B+1,).  Returns row_mask (uint8, shape of valid),
+    n_rows (B,) int32 (-1 where the reference raises ValueError), status (B,) int32 (GSF_SIM3_FLAG_FEW_ROWS / _ROWS_ALL / _ROWS_SEGMENT)."""
+    g = config or CONFIG
+    Bn = (offsets.numel() - 1) if offsets is not None else ts.shape[0]
+    N = 0 if offsets is not None else ts.shape[1]
+    mask = torch.empty(valid.shape, dtype=torch.uint8, device=ts.device)
+    n_rows, st = torch.empty((Bn,), dtype=torch.int32, device=ts.device), torch.empty((Bn,), dtype=torch.int32, device=ts.device)
+    check(_lib.load().gsf_sim3_fit_rows_batch_dev(context().handle, _p(ts), _p(gps), _p(valid), _p(offsets), Bn, N, int(g["sim3_ransac"]["min_samples"]),
+                                                  float(g["time_alignment"]["max_gps_gap_threshold"]), float(g["sim3_ransac"]["max_initial_duration"]),
+                                                  _p(mask), _p(n_rows), _p(st)))
+    return mask, n_rows, st
 
 
 def sim3_umeyama_batch(src, dst, offsets=None, mask=None):
@@ -329,10 +354,12 @@ def utm_inverse_batch(e, n, offsets, zone, south):
     return lat, lon
 
 
-def fuse_pipeline_ragged(ts, pos, quat, gps, valid, offsets, config=None):
+def fuse_pipeline_ragged(ts, pos, quat, gps, valid, offsets, config=None, fit_rows=FIT_ROWS_DEFAULT):
     """Fused Umeyama -> Sim3(pose 0) -> EKF+RTS for trajectories of DIFFERENT lengths: flat device tensors ts (T,), pos (T,3),
-    quat (T,4), gps (T,3), valid (T,) uint8 and int64 offsets (B+1,).  Returns pos_out, quat_out, status, R, t, s."""
+    quat (T,4), gps (T,3), valid (T,) uint8 and int64 offsets (B+1,); fit_rows as in fuse_pipeline_batch.  Returns pos_out, quat_out,
+    status, R, t, s."""
     cfg = EkfConfig.from_config(config or CONFIG)
+    context().set_sim3_rows(fit_rows, config or CONFIG)
     B = offsets.numel() - 1
     f = dict(dtype=torch.float64, device=ts.device)
     po, qo = torch.empty_like(pos), torch.empty_like(quat)

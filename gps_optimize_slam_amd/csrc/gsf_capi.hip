@@ -159,7 +159,19 @@ using namespace gsf;
 
 extern "C" {
 
-const char* gsf_version(void) { return "gsf 0.1.0 (gfx950, fp64)"; }
+// The wave-per-trajectory kernels live in two translation units that are compiled with different instruction schedulers (Makefile); which
+// scheduler and which floating-point contraction mode actually produced each object is part of the version string, so a build that took
+// the Makefile's fall-back path cannot ship unnoticed (bench.py prints this string).
+const char* gsf_version(void)
+{
+    static char buf[640];
+    static bool done = false;
+    if (!done) {
+        snprintf(buf, sizeof buf, "gsf 0.4.0 (gfx950, fp64) | %s | %s | %s", gsf::wave_small_build_info(), gsf::wave_big_build_info(), gsf::wave_block_build_info());
+        done = true;
+    }
+    return buf;
+}
 int gsf_abi_version(void) { return GSF_ABI_VERSION; }
 
 int gsf_last_error(char* buf, int n)
@@ -191,16 +203,24 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
     c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr; c->k2b_screen = 1; c->k2b_scratch = nullptr; c->k2b_scratch_bytes = 0;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
-    // kernel-choice override for A/B runs of the whole test suite (the same meaning as gsf_set_option "block_kernel")
-    if (const char* e = getenv("GSF_BLOCK_KERNEL")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->block_kernel = v; }
+    c->fit_rows = gsf::FitRows{ 0, 4, 5.0, 180.0 };                        // every valid row; the numbers are the reference's CONFIG defaults (:34, :53, :37)
     if (owns) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail_hip(e, "hipStreamCreateWithFlags"); }
     }
+    // on a failure everything created so far is released again, and the message names the call that failed
+    bool have_ev0 = false, have_ev1 = false;
+    const char* what = "hipEventCreate";
     hipError_t e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc(&c->small_scratch, 512);
-    if (e != hipSuccess) { delete c; return fail_hip(e, "hipEventCreate"); }
+    if (e == hipSuccess) { have_ev0 = true; e = hipEventCreate(&c->ev1); }
+    if (e == hipSuccess) { have_ev1 = true; what = "hipMalloc(small_scratch)"; e = hipMalloc(&c->small_scratch, 512); }
+    if (e != hipSuccess) {
+        if (have_ev0) (void)hipEventDestroy(c->ev0);
+        if (have_ev1) (void)hipEventDestroy(c->ev1);
+        if (owns) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail_hip(e, what);
+    }
     *out = c;
     return GSF_OK;
 }
@@ -223,6 +243,19 @@ void gsf_destroy(gsf_ctx* ctx)
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int gsf_trim(gsf_ctx* ctx)
+{
+    GSF_REQUIRE(ctx, "ctx is NULL");
+    GSF_HIP(hipSetDevice(ctx->device));
+    GSF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) { GSF_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    if (ctx->rng_scratch) { GSF_HIP(hipFree(ctx->rng_scratch)); ctx->rng_scratch = nullptr; ctx->rng_scratch_bytes = 0; }
+    if (ctx->k2b_scratch) { GSF_HIP(hipFree(ctx->k2b_scratch)); ctx->k2b_scratch = nullptr; ctx->k2b_scratch_bytes = 0; }
+    if (ctx->stage) { GSF_HIP(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    if (ctx->pinned) { GSF_HIP(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+    return GSF_OK;
 }
 
 int gsf_synchronize(gsf_ctx* ctx)
@@ -262,6 +295,15 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     }
     set_error("gsf_set_option: unknown key '%s'", key);
     return GSF_ERR_INVALID_ARG;
+}
+
+int gsf_set_sim3_rows(gsf_ctx* ctx, int32_t mode, int32_t min_samples, double max_gps_gap_threshold, double max_initial_duration)
+{
+    GSF_REQUIRE(ctx, "ctx is NULL");
+    GSF_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (all valid rows) or 1 (the reference's choice, EKFGPSSLAM.py:973-998)");
+    GSF_REQUIRE(mode == 0 || min_samples >= 0, "min_samples must be >= 0");
+    ctx->fit_rows = gsf::FitRows{ mode, min_samples, max_gps_gap_threshold, max_initial_duration };
+    return GSF_OK;
 }
 
 int gsf_timer_start(gsf_ctx* ctx)
@@ -429,6 +471,25 @@ int gsf_fuse_pipeline_batch(gsf_ctx* ctx, int32_t layout, const double* ts, cons
     double* dR = st.out(R, (size_t)B * 9); double* dt = st.out(t, (size_t)B * 3); double* ds = st.out(s, (size_t)B);
     double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dst_ = st.out(status, (size_t)B);
     ST_RUN(gsf_fuse_pipeline_batch_dev(ctx, layout, dts, dpos, dquat, dgps, dval, cfg, B, N, dR, dt, ds, dpo, dqo, dst_));
+}
+
+// main_process_gui's row choice (ref :973-998), host arrays
+int gsf_sim3_fit_rows_batch(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
+                            int32_t min_samples, double max_gps_gap_threshold, double max_initial_duration, uint8_t* row_mask, int32_t* n_rows,
+                            int32_t* status)
+{
+    GSF_REQUIRE(ctx && B >= 0 && (offsets || N >= 0), "bad arguments");
+    if (B == 0 || (!offsets && N == 0)) return GSF_OK;
+    GSF_REQUIRE(ts && valid && row_mask && n_rows, "NULL array");
+    const int64_t total = offsets ? offsets[B] : B * N;
+    GSF_REQUIRE(total >= 0, "bad offsets");
+    if (total == 0) { for (int64_t b = 0; b < B; ++b) { n_rows[b] = -1; if (status) status[b] = GSF_SIM3_FLAG_FEW_ROWS; } return GSF_OK; }
+    const size_t P = (size_t)total;
+    ST_BEGIN(P * 34 + (size_t)B * 16 + 64, 8);
+    const double* dts = st.in(ts, P); const double* dgps = gps ? st.in(gps, P * 3) : nullptr; const uint8_t* dval = st.in(valid, P);
+    const int64_t* doff = offsets ? st.in(offsets, (size_t)B + 1) : nullptr;
+    uint8_t* dmask = st.out(row_mask, P); int32_t* dn = st.out(n_rows, (size_t)B); int32_t* dst_ = status ? st.out(status, (size_t)B) : nullptr;
+    ST_RUN(gsf_sim3_fit_rows_batch_dev(ctx, dts, dgps, dval, doff, B, N, min_samples, max_gps_gap_threshold, max_initial_duration, dmask, dn, dst_));
 }
 
 // the same steps with the reference's robust fit; mt_state[B][625] (host, in/out) is each trajectory's NumPy legacy generator state

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64, OCC) void ekf_fuse_kernel(const double* __restr
 template <int LAYOUT, int PF, int OCC>
 __global__ __launch_bounds__(64, OCC) void fuse_pipeline_kernel(const double* __restrict__ ts, const double* __restrict__ pos,
                                                            const double* __restrict__ quat, const double* __restrict__ gps,
-                                                           const uint8_t* __restrict__ valid, EkfConfig cfg, int64_t B, int64_t N,
+                                                           const uint8_t* __restrict__ valid, EkfConfig cfg, FitRows rows, int64_t B, int64_t N,
                                                            double* __restrict__ Rout, double* __restrict__ tout, double* __restrict__ sout,
                                                            double* __restrict__ pos_out, double* __restrict__ quat_out,
                                                            int32_t* __restrict__ status)
@@ -114,26 +114,65 @@ __global__ __launch_bounds__(64, OCC) void fuse_pipeline_kernel(const double* __
     if (b >= B) return;
     LaneIO<LAYOUT> io{ B, N, b, ts, pos, quat, gps, valid, pos_out, quat_out };
     const Idx<LAYOUT> ix{ B, N };
-    // ---- pass A
+    // ---- pass A.  Under gsf_set_sim3_rows mode 1 the rows are main_process_gui's choice (ref :973-998): serial per lane, so the row in
+    // front of the gap (left out by V[:k], :981-982) is simply held back -- a valid row is accumulated when the NEXT valid row has been
+    // seen not to open a gap, or at the end of the track; the two fall-backs repeat the pass for the lanes that need them.
     double n = 0.0, as[3] = { 0, 0, 0 }, bs[3] = { 0, 0, 0 }, Sa[3] = { 0, 0, 0 }, Sb[3] = { 0, 0, 0 }, Saa = 0.0;
     double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    for (int64_t i = 0; i < N; ++i) {
-        const double z0 = gps[ix.at(b, i, 0, 3)], z1 = gps[ix.at(b, i, 1, 3)], z2 = gps[ix.at(b, i, 2, 3)];
-        const bool ok = valid[ix.at(b, i, 0, 1)] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
-        const double p0 = pos[ix.at(b, i, 0, 3)], p1 = pos[ix.at(b, i, 1, 3)], p2 = pos[ix.at(b, i, 2, 3)];
-        if (!ok) continue;
-        if (n == 0.0) { as[0] = p0; as[1] = p1; as[2] = p2; bs[0] = z0; bs[1] = z1; bs[2] = z2; }
-        const double a0 = p0 - as[0], a1 = p1 - as[1], a2 = p2 - as[2];
-        const double c0 = z0 - bs[0], c1 = z1 - bs[1], c2 = z2 - bs[2];
-        Sa[0] += a0; Sa[1] += a1; Sa[2] += a2; Sb[0] += c0; Sb[1] += c1; Sb[2] += c2;
-        Saa += a0 * a0 + a1 * a1 + a2 * a2;
-        Sab[0] += a0 * c0; Sab[1] += a0 * c1; Sab[2] += a0 * c2;
-        Sab[3] += a1 * c0; Sab[4] += a1 * c1; Sab[5] += a1 * c2;
-        Sab[6] += a2 * c0; Sab[7] += a2 * c1; Sab[8] += a2 * c2;
-        n += 1.0;
+    int32_t rows_flag = 0;
+    const bool ref_rows = rows.mode != 0;
+    int state = ref_rows ? 0 : 2;                                        // 0 the timed subset, 1 the whole first segment, 2 all valid rows
+    bool detect = ref_rows, use_tlim = ref_rows;
+    int64_t row_end = N;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        n = 0.0; Saa = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Sa[k] = 0.0; Sb[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sab[k] = 0.0;
+        bool have_first = false, have_pend = false, pend_in = false, gap_found = false;
+        double tlim = 0.0, t_pend = 0.0, pa[3] = { 0, 0, 0 }, pc[3] = { 0, 0, 0 };
+        int64_t i_pend = 0;
+        int nvalid = 0;
+        auto accumulate = [&](const double a0, const double a1, const double a2, const double c0, const double c1, const double c2) __attribute__((always_inline)) {
+            Sa[0] += a0; Sa[1] += a1; Sa[2] += a2; Sb[0] += c0; Sb[1] += c1; Sb[2] += c2;
+            Saa += a0 * a0 + a1 * a1 + a2 * a2;
+            Sab[0] += a0 * c0; Sab[1] += a0 * c1; Sab[2] += a0 * c2;
+            Sab[3] += a1 * c0; Sab[4] += a1 * c1; Sab[5] += a1 * c2;
+            Sab[6] += a2 * c0; Sab[7] += a2 * c1; Sab[8] += a2 * c2;
+            n += 1.0;
+        };
+        for (int64_t i = 0; i < N && i < row_end; ++i) {
+            const double z0 = gps[ix.at(b, i, 0, 3)], z1 = gps[ix.at(b, i, 1, 3)], z2 = gps[ix.at(b, i, 2, 3)];
+            const bool ok = valid[ix.at(b, i, 0, 1)] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
+            const double p0 = pos[ix.at(b, i, 0, 3)], p1 = pos[ix.at(b, i, 1, 3)], p2 = pos[ix.at(b, i, 2, 3)];
+            if (!ok) continue;
+            if (!have_first) { as[0] = p0; as[1] = p1; as[2] = p2; bs[0] = z0; bs[1] = z1; bs[2] = z2; have_first = true; }
+            const double a0 = p0 - as[0], a1 = p1 - as[1], a2 = p2 - as[2];
+            const double c0 = z0 - bs[0], c1 = z1 - bs[1], c2 = z2 - bs[2];
+            if (!ref_rows) { accumulate(a0, a1, a2, c0, c1, c2); continue; }
+            const double t = ts[ix.at(b, i, 0, 1)];
+            if (nvalid == 0) tlim = t + rows.max_dur;                    // segment_start_time + max_dur (:988-990)
+            if (have_pend) {
+                if (detect && t - t_pend > rows.max_gap) { gap_found = true; row_end = i_pend; break; }   // np.diff > threshold (:979-982): V[:k] drops the held-back row too
+                if (pend_in) accumulate(pa[0], pa[1], pa[2], pc[0], pc[1], pc[2]);
+            }
+            pa[0] = a0; pa[1] = a1; pa[2] = a2; pc[0] = c0; pc[1] = c1; pc[2] = c2;
+            t_pend = t; i_pend = i; have_pend = true; pend_in = !use_tlim || t <= tlim; ++nvalid;
+        }
+        if (!ref_rows) break;
+        if (have_pend && !gap_found && pend_in) accumulate(pa[0], pa[1], pa[2], pc[0], pc[1], pc[2]);
+        if (state != 0) { if (state == 2 && nvalid < rows.min_samples) rows_flag = SIM3_FLAG_FEW_ROWS; break; }   // :975
+        const int nF = gap_found ? nvalid - 1 : nvalid;                  // valid rows in front of the held-back one
+        detect = false;
+        if (nF < rows.min_samples) {                                     // :983
+            if (!gap_found) { rows_flag = SIM3_FLAG_FEW_ROWS; break; }   // V itself is that short (:975)
+            row_end = N; use_tlim = false; state = 2; rows_flag = SIM3_FLAG_ROWS_ALL;      // :984
+        } else if ((int)n < rows.min_samples) { use_tlim = false; state = 1; rows_flag = SIM3_FLAG_ROWS_SEGMENT; }   // :993-995
+        else break;                                                      // :996
     }
     double Rb[9], tb[3], sb = NAN; int32_t fit = SIM3_NONE;
-    if (n >= 3.0) {
+    if (n >= 3.0 && !(rows_flag & SIM3_FLAG_FEW_ROWS)) {
         const double rn = 1.0 / n;
         const double ma[3] = { Sa[0] * rn, Sa[1] * rn, Sa[2] * rn }, mb[3] = { Sb[0] * rn, Sb[1] * rn, Sb[2] * rn };
         double H[9];
@@ -152,9 +191,10 @@ __global__ __launch_bounds__(64, OCC) void fuse_pipeline_kernel(const double* __
         tout[b * 3] = tout[b * 3 + 1] = tout[b * 3 + 2] = NAN; sout[b] = NAN;
         const Vec3 pn{ NAN, NAN, NAN }; const Quat qn{ NAN, NAN, NAN, NAN };
         for (int64_t i = 0; i < N; ++i) io.store(i, pn, qn);
-        if (status) status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
+        if (status) status[b] = (fit == SIM3_NONE ? ((SIM3_NONE | (rows_flag & SIM3_FLAG_FEW_ROWS)) << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
         return;
     }
+    fit |= rows_flag;
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = Rb[k];
     tout[b * 3] = tb[0]; tout[b * 3 + 1] = tb[1]; tout[b * 3 + 2] = tb[2]; sout[b] = sb;
@@ -270,7 +310,7 @@ extern "C" int gsf_fuse_pipeline_batch_dev(gsf_ctx* ctx, int32_t layout, const d
         return fuse_time_major_via_wave(ctx, true, ts, pos, quat, gps, valid, nullptr, nullptr, cfg, B, N, R, t, s, pos_out, quat_out, status);
     const EkfConfig k = to_core(cfg);
     const dim3 block(64), grid((unsigned)((B + 63) / 64));
-    hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, B, N,
+    hipLaunchKernelGGL((fuse_pipeline_kernel<GSF_LAYOUT_TIME_MAJOR, 2, 2>), grid, block, 0, ctx->stream, ts, pos, quat, gps, valid, k, ctx->fit_rows, B, N,
                        R, t, s, pos_out, quat_out, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;

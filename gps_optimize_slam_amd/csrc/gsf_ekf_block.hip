@@ -592,7 +592,7 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
                      int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status)
 {
     GSF_REQUIRE(B <= 0x7fffffff && ekf_block_applies(N, nullptr), "launch_ekf_block: needs 64 < N <= 1024");
-    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, nullptr };
+    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, nullptr, FitRows{ 0, 0, 0.0, 0.0 } };
     const EkfConfig k = to_core_block(cfg);
     const bool xy = k.P0[1] == k.P0[0] && k.Qps[1] == k.Qps[0] && k.Rm[1] == k.Rm[0] &&
                     !(k.P0[2] == k.P0[0] && k.Qps[2] == k.Qps[0] && k.Rm[2] == k.Rm[0]);
@@ -612,3 +612,5 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
 }
 
 }  // namespace gsf
+
+namespace gsf { const char* wave_block_build_info() { return GSF_TU_BUILD_INFO("gsf_ekf_block.hip"); } }

@@ -38,6 +38,14 @@ struct EkfConfig {                 // CONFIG['ekf'] + CONFIG['rts_decision'], re
     int32_t _pad;
 };
 
+// Which time-synchronised rows feed the Sim3 fit of the fused chains (gsf_set_sim3_rows): mode 0 = every row with valid finite GNSS,
+// mode 1 = the choice of main_process_gui (ref :973-998: first gap-free segment, <= max_initial_duration, two fall-backs)
+struct FitRows {
+    int32_t mode, min_samples;     // CONFIG['sim3_ransac']['min_samples'] (:34)
+    double max_gap;                // CONFIG['time_alignment']['max_gps_gap_threshold'] (:53)
+    double max_dur;                // CONFIG['sim3_ransac']['max_initial_duration'] (:37)
+};
+
 enum : int32_t {                   // per-trajectory status bits (include/gsf.h)
     ST_HAD_OUTAGE = 1, ST_RTS_APPLIED = 2, ST_SHARP_TURN = 4, ST_ENDED_IN_OUTAGE = 8, ST_BAD_QUAT = 16
 };

@@ -73,9 +73,10 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     // tracks of 65..1024 poses: one workgroup per trajectory, one wave per chunk (gsf_ekf_block.hip).  The choice depends on N and the
     // layout only, never on B, so a shard of a batch produces the same bits as the whole batch.
-    if (ctx->block_kernel == 1 && ekf_block_applies(N, offsets))
+    // (its fit is a cross-wave reduction over ALL valid rows: a pipeline call under the reference's row choice stays with the wave kernel)
+    if (ctx->block_kernel == 1 && ekf_block_applies(N, offsets) && !(pipeline && ctx->fit_rows.mode != 0))
         return launch_ekf_block(ctx, pipeline, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status);
-    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets };
+    WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets, pipeline ? ctx->fit_rows : FitRows{ 0, 0, 0.0, 0.0 } };
     const EkfConfig k = to_core(cfg);
     // x and y share their (P0, Q, R) and z does not (the default CONFIG): the build with that choice of scans compiled in
     const bool xy = k.P0[1] == k.P0[0] && k.Qps[1] == k.Qps[0] && k.Rm[1] == k.Rm[0] &&
@@ -108,3 +109,5 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
 }
 
 }  // namespace gsf
+
+namespace gsf { const char* wave_small_build_info() { return GSF_TU_BUILD_INFO("gsf_ekf_wave.hip"); } }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     __shared__ int sh_nin[CH_MAX_TRIALS];
     __shared__ double sh_score[CH_MAX_TRIALS];
     __shared__ int32_t sh_end[CH_MAX_TRIALS];
-    __shared__ PolyModel sh_model[64];                                    // models of the batch being scored (batches are 8, 16, 32, then 64 trials)
+    __shared__ PolyModel sh_model[64];                                    // models of the batch being scored (batches are 4, 8, 16, 32, then 64 trials)
     extern __shared__ uint16_t dyn[];                                     // [jseq_elems] swap partners, then int32 idx[max_trials * ms]
     uint16_t* jseq = dyn;
     int32_t* sh_idx = (int32_t*)(dyn + ((jseq_elems + 1) & ~1));
@@ -338,12 +338,16 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                 if (nb <= 0) break;
                 mt_draw_choice(mt, pos_mt, n, nb, ms, jseq, jseq_elems, sh_idx + (size_t)drawn * ms, sh_end + drawn, lane);
                 // models: a lane per trial (at most 32 of them work); scores: the whole wave over the ROWS of one trial at a time -- a batch
-                // is 8-32 trials of ~150 rows, and a lane walking all rows of its trial alone was 44 of a window-axis's 85 us
+                // is 4-64 trials of ~150 rows, and a lane walking all rows of its trial alone was 44 of a window-axis's 85 us
                 for (int tau = lane; tau < nb; tau += 64) {
                     sh_model[tau] = fit_subset(tp, yp, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, 3);
                     sh_end[drawn + tau] += raw_base;                          // outputs consumed since the window-axis start
                 }
                 __syncthreads();
+                // (the R^2 score below is summed per lane and then across the wave; score_trial / ransac_poly_kernel of the fed-sample route
+                // sum row after row on one thread.  Equal inlier counts are ordered by the score with an exact compare, so a near-tie in the
+                // last ulp may resolve differently on the two routes -- scikit-learn's own order of summation is a third one; the sixteen
+                // reference runs and sixty live scikit-learn cases of the tests hold no such tie.)
                 for (int tau = 0; tau < nb; ++tau) {
                     const PolyModel m = sh_model[tau];
                     int cnt = 0; double sy = 0.0;

@@ -33,6 +33,7 @@ struct gsf_ctx {
     int synth_variant;     // synthetic workload (gsf_set_option "synth_variant"): 0 = white SLAM noise (default), 1 = SURVEY 8d's random-walk drift
     int block_kernel;      // workgroup-per-trajectory kernel for 64 < N <= 1024 (gsf_set_option "block_kernel"): -1 automatic, 0 never, 1 always
     int duo_kernel;        // two-wave pipeline kernel for small batches (gsf_set_option "duo_kernel"): -1 automatic, 0 never, 1 always
+    gsf::FitRows fit_rows; // rows of the fused chains' Sim3 fit (gsf_set_sim3_rows); mode 0 = all valid rows
     int64_t lane_min_traj; // time-major batches with fewer trajectories are transposed and run by the wave kernel (gsf_set_option "lane_min_traj")
 };
 
@@ -62,6 +63,18 @@ struct Idx {
         return (b * N + i) * C + c;
     }
 };
+
+// how each wave-level translation unit was compiled (scheduler, -ffp-contract mode, compiler): recorded by the Makefile's -D flags
+#ifndef GSF_TU_SCHED
+#define GSF_TU_SCHED "default"
+#endif
+#ifndef GSF_TU_CONTRACT
+#define GSF_TU_CONTRACT "fast (hipcc default)"
+#endif
+#define GSF_TU_BUILD_INFO(file) file ": sched=" GSF_TU_SCHED ", fp-contract=" GSF_TU_CONTRACT ", clang " __clang_version__
+const char* wave_small_build_info();
+const char* wave_big_build_info();
+const char* wave_block_build_info();
 
 int ensure_scratch(gsf_ctx* ctx, size_t bytes);
 int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes);

@@ -12,8 +12,77 @@ using namespace gsf;
 
 namespace {
 
-// one wave per trajectory: stable compaction of the rows with valid, finite GNSS into slot [b*N, b*N + n_b)
+// one wave per trajectory: which rows feed the Sim3 fit, main_process_gui's way (ref :973-998; gsf_set_sim3_rows mode 1,
+// gsf_sim3_fit_rows_batch_dev).  Pass 1 walks the valid rows for the first gap and counts what the duration limit keeps; the
+// reference's two fall-backs are decided from the counts; pass 2 writes the mask.
+__global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict__ ts, const double* __restrict__ gps, const uint8_t* __restrict__ valid,
+                                                       const int64_t* __restrict__ offsets, int64_t N, FitRows rule, uint8_t* __restrict__ row_mask,
+                                                       int32_t* __restrict__ n_rows, int32_t* __restrict__ status)
+{
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    int64_t base = b * N, n = N;
+    if (offsets) { base = uniform64(offsets[b]); n = uniform64(offsets[b + 1]) - base; }
+    const double* tsb = ts + base; const uint8_t* valb = valid + base; const double* gpsb = gps ? gps + base * 3 : nullptr;
+    auto row_ok = [&](const int64_t i) __attribute__((always_inline)) {
+        if (i >= n) return false;
+        bool ok = valb[i] != 0;
+        if (gpsb) ok = ok && !(isnan(gpsb[i * 3]) || isnan(gpsb[i * 3 + 1]) || isnan(gpsb[i * 3 + 2]));
+        return ok;
+    };
+    RowScan rs{ false, 0.0, 0, 0 };
+    bool gap_found = false, have_t0 = false, carry_in_T = false;
+    int64_t row_end = n;
+    int nF = 0, nT = 0;
+    double tlim = 0.0;
+    for (int64_t c0 = 0; c0 < n && !gap_found; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool ok = row_ok(i);
+        const double t = tsb[i < n ? i : n - 1];
+        const u64 m = __ballot(ok);
+        if (m == 0ull) continue;
+        if (!have_t0) { tlim = lane_bcast(t, __ffsll((long long)m) - 1) + rule.max_dur; have_t0 = true; }   // segment_start_time + max_dur (:988-990)
+        bool in_chunk = false;
+        gap_found = rows_gap_in_chunk(rs, m, t, ok, lane, c0, rule.max_gap, row_end, nF, in_chunk);
+        const u64 tm = __ballot(ok && t <= tlim);
+        if (gap_found) {
+            if (in_chunk) nT += __popcll(tm & bits(0, (int)(row_end - c0) - 1));
+            else nT -= carry_in_T ? 1 : 0;                                // the row in front of the gap is the carried one: it was counted, and V[:k] leaves it out
+        } else {
+            nT += __popcll(tm);
+            carry_in_T = ((tm >> (63 - __clzll((long long)m))) & 1ull) != 0ull;
+        }
+    }
+    if (!gap_found) nF = rs.nvalid;
+    bool use_tlim = true;
+    int32_t flag = 0; int count = nT;
+    if (nF < rule.min_samples) {                                          // :983
+        if (!gap_found) { flag = SIM3_FLAG_FEW_ROWS; count = -1; }       // :975
+        else { row_end = n; use_tlim = false; flag = SIM3_FLAG_ROWS_ALL; count = -2; }   // :984 (counted in pass 2)
+    } else if (nT < rule.min_samples) { use_tlim = false; flag = SIM3_FLAG_ROWS_SEGMENT; count = nF; }   // :993-995
+    int total = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool ok = row_ok(i);
+        const double t = tsb[i < n ? i : n - 1];
+        const bool sel = ok && flag != SIM3_FLAG_FEW_ROWS && i < row_end && (!use_tlim || t <= tlim);
+        total += __popcll(__ballot(sel));
+        if (i < n) row_mask[base + i] = sel ? 1 : 0;
+    }
+    if (count == -2) {                                                    // all valid rows: still fewer than min_samples -> ValueError (:975)
+        count = total;
+        if (total < rule.min_samples) {
+            flag = SIM3_FLAG_FEW_ROWS; count = -1;
+            for (int64_t i = lane; i < n; i += 64) row_mask[base + i] = 0;
+        }
+    }
+    if (lane == 0) { n_rows[b] = count; if (status) status[b] = flag; }
+}
+
+// one wave per trajectory: stable compaction of the rows with valid, finite GNSS -- or, under the reference's row choice, of the rows
+// `rowsel` marks -- into slot [b*N, b*N + n_b)
 __global__ __launch_bounds__(64) void compact_valid_kernel(const double* __restrict__ pos, const double* __restrict__ gps, const uint8_t* __restrict__ valid,
+                                                           const uint8_t* __restrict__ rowsel,
                                                            int64_t B, int64_t N, double* __restrict__ src, double* __restrict__ dst,
                                                            int32_t* __restrict__ rowmap, int32_t* __restrict__ counts, int64_t* __restrict__ offsets)
 {
@@ -26,7 +95,7 @@ __global__ __launch_bounds__(64) void compact_valid_kernel(const double* __restr
         double z0 = 0, z1 = 0, z2 = 0;
         if (i < N) {
             z0 = gps[(base + i) * 3]; z1 = gps[(base + i) * 3 + 1]; z2 = gps[(base + i) * 3 + 2];
-            ok = valid[base + i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2));
+            ok = rowsel ? rowsel[base + i] != 0 : (valid[base + i] != 0 && !(isnan(z0) || isnan(z1) || isnan(z2)));
         }
         const u64 m = __ballot(ok);
         if (ok) {
@@ -66,7 +135,7 @@ __global__ __launch_bounds__(64) void robust_init_pose_kernel(const double* __re
 
 // one wave per trajectory: status word, inlier mask in original row order, NaN rows when the fit is None / pose 0 is invalid
 __global__ __launch_bounds__(64) void robust_finish_kernel(int64_t N, const int32_t* __restrict__ fit, const int32_t* __restrict__ fail,
-                                                           const int32_t* __restrict__ counts, const int32_t* __restrict__ rowmap,
+                                                           const int32_t* __restrict__ rows_status, const int32_t* __restrict__ counts, const int32_t* __restrict__ rowmap,
                                                            const uint8_t* __restrict__ mask_c, uint8_t* __restrict__ inlier_mask,
                                                            double* __restrict__ pos_out, double* __restrict__ quat_out, int32_t* __restrict__ status)
 {
@@ -84,9 +153,10 @@ __global__ __launch_bounds__(64) void robust_finish_kernel(int64_t N, const int3
             pos_out[(base + i) * 3] = NAN; pos_out[(base + i) * 3 + 1] = NAN; pos_out[(base + i) * 3 + 2] = NAN;
             quat_out[(base + i) * 4] = NAN; quat_out[(base + i) * 4 + 1] = NAN; quat_out[(base + i) * 4 + 2] = NAN; quat_out[(base + i) * 4 + 3] = NAN;
         }
-        if (lane == 0) status[b] = ((f & 1) ? (SIM3_NONE << 8) : 0) | ((f & 2) ? ST_BAD_QUAT : 0);
+        const int32_t few = rows_status ? (rows_status[b] & SIM3_FLAG_FEW_ROWS) : 0;      // the reference raised ValueError before the fit (:975, :997)
+        if (lane == 0) status[b] = ((f & 1) ? ((SIM3_NONE | few) << 8) : 0) | ((f & 2) ? ST_BAD_QUAT : 0);
     } else if (lane == 0) {
-        status[b] = (status[b] & 0xff) | (fit[b] << 8);
+        status[b] = (status[b] & 0xff) | ((fit[b] | (rows_status ? rows_status[b] : 0)) << 8);
     }
 }
 
@@ -113,14 +183,22 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
     auto take = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes); return at; };
     const size_t o_src = take(P * 24), o_dst = take(P * 24), o_map = take(P * 4), o_mask = take(P), o_cnt = take(nb * 4), o_off = take((nb + 1) * 8),
                  o_idx = take(nb * (size_t)max_trials * (size_t)min_samples * 4 + 4), o_fit = take(nb * 4), o_fail = take(nb * 4), o_ip = take(nb * 24),
-                 o_iq = take(nb * 32);
+                 o_iq = take(nb * 32), o_sel = take(P), o_rst = take(nb * 4), o_rn = take(nb * 4);
     int rc = ensure_scratch(ctx, off);
     if (rc) return rc;
     char* w = (char*)ctx->scratch;
     double* src = (double*)(w + o_src); double* dst = (double*)(w + o_dst); int32_t* rowmap = (int32_t*)(w + o_map); uint8_t* mask_c = (uint8_t*)(w + o_mask);
     int32_t* counts = (int32_t*)(w + o_cnt); int64_t* offsets = (int64_t*)(w + o_off); int32_t* idx = (int32_t*)(w + o_idx);
     int32_t* fit = (int32_t*)(w + o_fit); int32_t* fail = (int32_t*)(w + o_fail); double* ip = (double*)(w + o_ip); double* iq = (double*)(w + o_iq);
-    hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, B, N, src, dst, rowmap, counts, offsets);
+    // the rows the fit may draw from: every valid row, or the reference's choice (ref :973-998)
+    uint8_t* rowsel = nullptr; int32_t* rows_status = nullptr;
+    if (ctx->fit_rows.mode != 0) {
+        rowsel = (uint8_t*)(w + o_sel); rows_status = (int32_t*)(w + o_rst);
+        hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
+                           (int32_t*)(w + o_rn), rows_status);
+        GSF_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, (const uint8_t*)rowsel, B, N, src, dst, rowmap, counts, offsets);
     GSF_HIP(hipGetLastError());
     if (max_trials > 0 && (rc = launch_mt_choice(ctx, mt_state, counts, B, max_trials, min_samples, idx, (int32_t)N))) return rc;
     if ((rc = launch_sim3_ransac(ctx, src, dst, offsets, counts, B, idx, max_trials, min_samples, residual_threshold, min_inliers_needed, R, t, s, fit,
@@ -128,7 +206,23 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
     hipLaunchKernelGGL(robust_init_pose_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, pos, quat, B, N, R, t, s, fit, ip, iq, fail);
     GSF_HIP(hipGetLastError());
     if ((rc = launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, ip, iq, cfg, B, N, nullptr, nullptr, nullptr, pos_out, quat_out, status))) return rc;
-    hipLaunchKernelGGL(robust_finish_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, N, fit, fail, counts, rowmap, mask_c, inlier_mask, pos_out, quat_out, status);
+    hipLaunchKernelGGL(robust_finish_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, N, fit, fail, (const int32_t*)rows_status, counts, rowmap, mask_c, inlier_mask, pos_out, quat_out, status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+// main_process_gui's row choice on its own (ref :973-998)
+extern "C" int gsf_sim3_fit_rows_batch_dev(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B,
+                                           int64_t N, int32_t min_samples, double max_gps_gap_threshold, double max_initial_duration,
+                                           uint8_t* row_mask, int32_t* n_rows, int32_t* status)
+{
+    GSF_REQUIRE(ctx, "ctx is NULL");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff && (offsets || N >= 0) && min_samples >= 0, "bad B, N or min_samples");
+    if (B == 0 || (!offsets && N == 0)) return GSF_OK;
+    GSF_REQUIRE(ts && valid && row_mask && n_rows, "NULL array");
+    GSF_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N,
+                       FitRows{ 1, min_samples, max_gps_gap_threshold, max_initial_duration }, row_mask, n_rows, status);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

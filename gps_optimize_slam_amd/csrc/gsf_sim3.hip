@@ -997,12 +997,13 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
     // double kernel's); needs the rows as floats in the workspace, hence their total number (0 = unknown to the host: double
     // throughout, as with gsf_set_option "k2b_screen" 0)
     const float* frows = nullptr; const double* fhdr = nullptr; const int32_t* ridx = nullptr;
-    if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows <= ((int64_t)1 << 31) && trials >= 64) {
+    if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows < ((int64_t)1 << 31) && trials >= 64) {   // (slots and row indices of the screen are int32)
         const size_t hdr_bytes = ((size_t)B * RANSAC_HDR * 8 + 255) & ~(size_t)255;
         const int rc = ensure_k2b_scratch(ctx, hdr_bytes + (size_t)total_rows * 28);
         if (rc) return rc;
         double* h = (double*)ctx->k2b_scratch; float* f = (float*)((char*)ctx->k2b_scratch + hdr_bytes); int32_t* ri = (int32_t*)(f + (size_t)total_rows * 6);
         hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, ri, h);
+        GSF_HIP(hipGetLastError());                                       // a failed staging launch must not leave the scoring kernels on unstaged rows
         frows = f; fhdr = h; ridx = ri;
     }
     if (B <= RANSAC_SPLIT_MAX_SETS && trials >= 256) {

@@ -150,6 +150,7 @@ struct WaveArgs {
     double* pos_out; double* quat_out; int32_t* status;
     int64_t B, N;
     const int64_t* offsets;                       // ragged batches: trajectory b = rows offsets[b]..offsets[b+1] (else b*N.., N rows)
+    FitRows rows;                                 // which rows feed the pipeline's fit (gsf_set_sim3_rows)
 };
 
 __device__ __forceinline__ int64_t uniform64(int64_t v)
@@ -309,14 +310,14 @@ template <> struct NextChunk<true> { typedef ChunkWide type; };
 // is None or pose 0's quaternion is invalid (wave-uniform).  sums = { n, Sa[3], Sb[3], Saa, Sab[9] } per lane.
 __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64_t b, const int64_t base, const int64_t N, const int lane,
                                                   const double* sums, const double* as_, const double* bs_, const Quat& qraw0,
-                                                  Vec3& p0, Quat& q0, int32_t& fit)
+                                                  Vec3& p0, Quat& q0, int32_t& fit, const int32_t rows_flag = 0)
 {
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
     const double n = wave_sum(sums[0]);
     double Rb[9], tb[3], sb = NAN;
     fit = SIM3_NONE;
-    if (n >= 3.0) {                                                       // ref :430
+    if (n >= 3.0 && !(rows_flag & SIM3_FLAG_FEW_ROWS)) {                  // ref :430 (and :975 / :997: the reference raised before it got here)
         const Sums16 S = wave_sum16(sums[1], sums[2], sums[3], sums[4], sums[5], sums[6], sums[7], sums[8], sums[9], sums[10], sums[11],
                                     sums[12], sums[13], sums[14], sums[15], sums[16], lane);
         const double rn = fast_rcp(n);                                    // n >= 3
@@ -344,10 +345,11 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
         if (lane == 0) {
             for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = NAN;
             a.t[b * 3] = a.t[b * 3 + 1] = a.t[b * 3 + 2] = NAN; a.s[b] = NAN;
-            if (GSF_STATUS_PTR(a)) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
+            if (GSF_STATUS_PTR(a)) a.status[b] = (fit == SIM3_NONE ? ((SIM3_NONE | (rows_flag & SIM3_FLAG_FEW_ROWS)) << 8) : 0) | (q0ok ? 0 : ST_BAD_QUAT);
         }
         return false;
     }
+    fit |= rows_flag;                                                     // informational: which of the reference's row sets was fitted
     if (lane == 0) {
         for (int k = 0; k < 9; ++k) a.R[b * 9 + k] = Rb[k];
         a.t[b * 3] = tb[0]; a.t[b * 3 + 1] = tb[1]; a.t[b * 3 + 2] = tb[2]; a.s[b] = sb;
@@ -358,6 +360,152 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
     q0 = quat_mul(quat_from_matrix(Rb), qn0);                            // ref :465-466
     GSF_STAMP(5);
     return true;
+}
+
+// ---- the Sim3 row choice of main_process_gui (ref :973-998) inside a wave.  The valid rows V are walked 64 at a time; what travels
+// from chunk to chunk (wave-uniform) is the last valid row seen so far -- its stamp, its index, and how many valid rows there are up
+// to and including it.
+struct RowScan { bool have_prev; double t_prev; int64_t i_prev; int nvalid; };
+// One chunk of the walk: m = ballot of the valid rows of the chunk whose first row is c0, t = this lane's stamp.  A gap is a valid
+// row whose stamp exceeds the PREVIOUS VALID row's by more than max_gap (np.diff of the valid rows' stamps, :979-980).  On the first
+// gap: row_end = index of that previous valid row -- the segment is V[:k] with k the index of the diff, so the row in front of the gap
+// is left out as well (:981-982) -- nF = the number of valid rows before it, in_chunk = whether it sits in this chunk (else it is the
+// carried row).  Returns true on a gap; otherwise advances the carry.
+__device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, const double t, const bool ok, const int lane, const int64_t c0,
+                                                  const double max_gap, int64_t& row_end, int& nF, bool& in_chunk)
+{
+    if (m == 0ull) return false;
+    const u64 lower = m & bits(0, lane - 1);                              // valid rows of the chunk in front of this lane
+    const int pl = lower != 0ull ? 63 - __clzll((long long)lower) : 0;
+    const double tp_in = shidx(t, pl);
+    const double tp = lower != 0ull ? tp_in : rs.t_prev;
+    const bool gp = ok && (lower != 0ull || rs.have_prev) && (t - tp > max_gap);
+    const u64 g = __ballot(gp);
+    if (g != 0ull) {
+        const int gl = __ffsll((long long)g) - 1;
+        const u64 lg = m & bits(0, gl - 1);
+        if (lg != 0ull) {
+            const int ipl = 63 - __clzll((long long)lg);
+            row_end = c0 + ipl; nF = rs.nvalid + __popcll(m & bits(0, ipl - 1)); in_chunk = true;
+        } else { row_end = rs.i_prev; nF = rs.nvalid - 1; in_chunk = false; }
+        return true;
+    }
+    const int hl = 63 - __clzll((long long)m);
+    rs.t_prev = lane_bcast(t, hl); rs.i_prev = c0 + hl; rs.have_prev = true; rs.nvalid += __popcll(m);
+    return false;
+}
+
+// The pipeline's moments pass under gsf_set_sim3_rows mode 1: the same one-pass shifted moments as in wave_prelude below, over the rows
+// main_process_gui would hand to its fit (ref :973-998).  The first attempt looks for the gap WHILE it accumulates the rows that pass
+// the duration limit -- the rounds stop at the gap, so an outage track reads less than before, not more -- and only what the
+// reference's two fall-backs need costs a second pass: all valid rows when the first segment has fewer than min_samples rows
+// (:984-986), the whole segment when the limit leaves fewer than min_samples (:993-995).  (One more case repeats the pass: the gap is
+// found in a later ROUND than the row in front of it, which has been accumulated by then and does not belong to V[:k].)
+// sums = { n, Sa[3], Sb[3], Saa, Sab[9] } per lane, bs_ = the GNSS-side shift; rows_flag = SIM3_FLAG_FEW_ROWS / _ROWS_ALL / _ROWS_SEGMENT.
+#ifndef GSF_ROWS_ROUND
+#define GSF_ROWS_ROUND 6                                                  // chunks per round of this pass (the big-batch build takes fewer: registers)
+#endif
+template <int MOM_ROUND>
+__device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, const int64_t base, const int64_t N, const int lane,
+                                                           const double as0, const double as1, const double as2, double* sums, double* bs_,
+                                                           int32_t& rows_flag)
+{
+    const double* __restrict__ tsb = a.ts + base;
+    const double* __restrict__ posb = a.pos + base * 3;
+    const double* __restrict__ gpsb = a.gps + base * 3;
+    const uint8_t* __restrict__ valb = a.valid + base;
+    const int ms = a.rows.min_samples;
+    const double max_gap = a.rows.max_gap, max_dur = a.rows.max_dur;
+    bool detect = true, use_tlim = true, gap_found = false;
+    int64_t row_end = N;
+    int nF = 0, state = 0;                                               // state 0: the timed subset, 1: the whole first segment, 2: all valid rows
+    rows_flag = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0, tlim = 0.0;
+        bool have_shift = false, over = false;
+        RowScan rs{ false, 0.0, 0, 0 };
+        int nT = 0;
+        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+        double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int64_t c0 = 0; c0 < N && c0 < row_end; c0 += 64 * MOM_ROUND) {
+            double pa[MOM_ROUND][3], pz[MOM_ROUND][3], pt[MOM_ROUND]; uint32_t pv[MOM_ROUND];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) {
+                if (c0 + 64 * k < N) {                                    // wave-uniform
+                    const int64_t i = c0 + 64 * k + lane, il = i < N ? i : N - 1;
+                    pa[k][0] = posb[il * 3]; pa[k][1] = posb[il * 3 + 1]; pa[k][2] = posb[il * 3 + 2];
+                    pz[k][0] = gpsb[il * 3]; pz[k][1] = gpsb[il * 3 + 1]; pz[k][2] = gpsb[il * 3 + 2];
+                    pt[k] = tsb[il]; pv[k] = valb[il];
+                } else {
+                    pa[k][0] = pa[k][1] = pa[k][2] = 0.0; pz[k][0] = pz[k][1] = pz[k][2] = 0.0; pt[k] = 0.0; pv[k] = 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) asm volatile("" : "+v"(pv[k]));   // (see wave_prelude: one memory round trip per round)
+            bool ok[MOM_ROUND];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k)
+                ok[k] = (c0 + 64 * k + lane < N) && pv[k] != 0 && !(isnan(pz[k][0]) || isnan(pz[k][1]) || isnan(pz[k][2]));
+            if (!have_shift) {                                            // the first valid row: GNSS-side shift and segment_start_time (:988)
+                u64 msel = 0ull; int ksel = -1;
+#pragma unroll
+                for (int k = MOM_ROUND - 1; k >= 0; --k) { const u64 m = __ballot(ok[k]); if (m != 0ull) { msel = m; ksel = k; } }
+                if (ksel >= 0) {
+                    double v0 = pz[0][0], v1 = pz[0][1], v2 = pz[0][2], vt = pt[0];
+#pragma unroll
+                    for (int k = 1; k < MOM_ROUND; ++k) { const bool pick = (ksel == k); v0 = pick ? pz[k][0] : v0; v1 = pick ? pz[k][1] : v1; v2 = pick ? pz[k][2] : v2; vt = pick ? pt[k] : vt; }
+                    const int f = __ffsll((long long)msel) - 1;
+                    bs0 = lane_bcast(v0, f); bs1 = lane_bcast(v1, f); bs2 = lane_bcast(v2, f);
+                    tlim = lane_bcast(vt, f) + max_dur;                   // segment_start_time + max_dur (:989-990)
+                    have_shift = true;
+                }
+            }
+            if (detect && !gap_found) {
+#pragma unroll
+                for (int k = 0; k < MOM_ROUND; ++k) {
+                    if (!gap_found && c0 + 64 * k < N) {                  // wave-uniform
+                        bool in_chunk = false;
+                        gap_found = rows_gap_in_chunk(rs, __ballot(ok[k]), pt[k], ok[k], lane, c0 + 64 * k, max_gap, row_end, nF, in_chunk);
+                        if (gap_found && !in_chunk && row_end < c0) over = true;   // the row in front of the gap was accumulated a round ago
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) {
+                if (c0 + 64 * k < N) {                                    // wave-uniform
+                    const bool o = ok[k] && (c0 + 64 * k + lane < row_end) && (!use_tlim || pt[k] <= tlim);
+                    nT += __popcll(__ballot(o));
+                    const double a0 = o ? pa[k][0] - as0 : 0.0, a1 = o ? pa[k][1] - as1 : 0.0, a2 = o ? pa[k][2] - as2 : 0.0;
+                    const double b0 = o ? pz[k][0] - bs0 : 0.0, b1 = o ? pz[k][1] - bs1 : 0.0, b2 = o ? pz[k][2] - bs2 : 0.0;
+                    cnt += o ? 1.0 : 0.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
+                    Saa += a0 * a0 + a1 * a1 + a2 * a2;
+                    Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
+                    Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
+                    Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
+                }
+            }
+        }
+        sums[0] = cnt; sums[1] = Sa0; sums[2] = Sa1; sums[3] = Sa2; sums[4] = Sb0; sums[5] = Sb1; sums[6] = Sb2; sums[7] = Saa;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sums[8 + k] = Sab[k];
+        bs_[0] = bs0; bs_[1] = bs1; bs_[2] = bs2;
+        if (detect) {
+            detect = false;
+            if (!gap_found) nF = rs.nvalid;                               // no gap: the first segment is all of V (:981)
+            if (over) continue;                                           // once more, with the bound known from the start
+        }
+        // the sums now belong to exactly the rows (row_end, use_tlim) describe
+        if (state == 0) {
+            if (nF < ms) {                                                // :983
+                if (!gap_found) { rows_flag = SIM3_FLAG_FEW_ROWS; break; }           // V itself is that short: ValueError (:975)
+                row_end = N; use_tlim = false; state = 2; rows_flag = SIM3_FLAG_ROWS_ALL; continue;       // :984
+            }
+            if (nT < ms) { use_tlim = false; state = 1; rows_flag = SIM3_FLAG_ROWS_SEGMENT; continue; }   // :993-995
+            break;                                                        // :996
+        }
+        if (state == 2 && nT < ms) rows_flag = SIM3_FLAG_FEW_ROWS;        // fewer than min_samples valid rows in all: ValueError (:975)
+        break;
+    }
 }
 
 // Initial pose of trajectory b: either the caller's Sim3-aligned pose 0, or (PIPELINE) the Umeyama fit on the rows with valid
@@ -383,11 +531,20 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
         // The GNSS-side shift (first valid finite fix, wave-uniform) is found in the same pass: nothing is accumulated before it.
         const double as0 = posb[0], as1 = posb[1], as2 = posb[2];
         const Quat qraw0{ quatb[0], quatb[1], quatb[2], quatb[3] };      // pose 0's quaternion: requested here, used after the fit
+        constexpr int MOM_ROUND = 6;
+        if (a.rows.mode != 0) {                                           // wave-uniform: the reference's row choice (ref :973-998)
+            double sums[17], bs_[3]; int32_t rows_flag = 0;
+            fit_moments_reference_rows<GSF_ROWS_ROUND>(a, base, N, lane, as0, as1, as2, sums, bs_, rows_flag);
+            GSF_STAMP(2);
+            const double as_[3] = { as0, as1, as2 };
+            if (!fit_from_partials(a, b, base, N, lane, sums, as_, bs_, qraw0, p0, q0, fit, rows_flag)) return false;
+            p0_out = p0; q0_out = q0; fit_out = fit;
+            return true;
+        }
         double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
         bool have_shift = false;
         double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
         double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        constexpr int MOM_ROUND = 6;
         for (int64_t c0 = 0; c0 < N; c0 += 64 * MOM_ROUND) {
             double pa[MOM_ROUND][3], pz[MOM_ROUND][3]; uint32_t pv[MOM_ROUND];
 #pragma unroll

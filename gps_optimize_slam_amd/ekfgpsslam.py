@@ -586,19 +586,16 @@ def pick_sim3_indices(slam_data, valid_mask, config=None):
     return first if len(timed) < ms else timed
 
 
-def benchmark_c1(repeats=20, golden_dir=None):
-    """Warm wall time of the single-trajectory drop-in at the C1 shape (BASELINE configs[0]: the 271-pose KITTI-04 track and its
-    279 raw GNSS fixes, taken from the committed fixtures tests/golden/{kat_bundled,c1_combined}.npz -- data only): the GPS leg of
-    step 1 (projection + sliding RANSAC pre-filter, ref :266-275), steps 2-5 (time alignment, robust Sim3, apply, EKF+RTS,
-    ref :971-1010) and step 6 (error metric).  BASELINE.md's CPU figures for the reference: ~0.11 s for steps 2-5, 23-40 ms for
-    the pre-filter."""
-    import os
+def benchmark_c1(slam, gps_t_raw, lat, lon, alt, repeats=20):
+    """Warm wall time of the single-trajectory drop-in on ONE track handed in by the caller: slam = {'timestamps', 'positions',
+    'quaternions'} and its raw GNSS log (stamps, lat, lon, alt as load_gps_data reads them, ref :258).  Timed: the GPS leg of step 1
+    (projection + sliding RANSAC pre-filter, ref :266-275), steps 2-5 (time alignment, row choice, robust Sim3, apply, EKF+RTS,
+    ref :971-1010) and step 6 (error metric).  (bench.py feeds it the C1 shape -- BASELINE configs[0]: the 271-pose KITTI-04 track and
+    its 279 fixes from the committed fixtures; BASELINE.md has the reference's CPU figures: ~0.11 s for steps 2-5, 23-40 ms for the
+    pre-filter.)"""
     import time
-    if golden_dir is None:
-        golden_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-    k, g = np.load(os.path.join(golden_dir, "kat_bundled.npz")), np.load(os.path.join(golden_dir, "c1_combined.npz"))
-    slam = {"timestamps": k["ts"].copy(), "positions": k["pos"].copy(), "quaternions": k["quat"].copy()}
-    ts, lats, lons, alts = g["gps_t_raw"].copy(), g["lat"].copy(), g["lon"].copy(), g["alt"].copy()
+    slam = {k: np.array(slam[k], dtype=np.float64) for k in ("timestamps", "positions", "quaternions")}
+    ts, lats, lons, alts = (np.array(a, dtype=np.float64) for a in (gps_t_raw, lat, lon, alt))
     config = copy.deepcopy(CONFIG)
     sc = config["sim3_ransac"]
 

@@ -73,6 +73,11 @@ typedef struct {
 #define GSF_SIM3_FLAG_SVD_FALLBACK 16 /* informational (fused pipeline): the closed form's rotation came from the Jacobi SVD because the
                                          polar iteration declined this cross-covariance (rank-deficient / weakly separated reflection);
                                          same result to ~1e-14, only slower */
+/* row choice of the fused chains under gsf_set_sim3_rows mode 1 (main_process_gui, EKFGPSSLAM.py:973-998) */
+#define GSF_SIM3_FLAG_FEW_ROWS 32     /* fewer than min_samples time-synchronised rows: the reference raises ValueError (:975, :997);
+                                         comes with GSF_SIM3_NONE, NaN outputs, and (robust chain) an untouched generator */
+#define GSF_SIM3_FLAG_ROWS_ALL 64     /* informational: the first gap-free segment is shorter than min_samples -> all valid rows (:984-986) */
+#define GSF_SIM3_FLAG_ROWS_SEGMENT 128 /* informational: fewer than min_samples rows inside max_initial_duration -> the whole first segment (:993-995) */
 
 /* status bits of a fused trajectory */
 #define GSF_ST_HAD_OUTAGE 1
@@ -96,6 +101,14 @@ GSF_API int gsf_create(int device_id, gsf_ctx **out);
 GSF_API int gsf_create_on_stream(int device_id, void *hip_stream, gsf_ctx **out);
 GSF_API void gsf_destroy(gsf_ctx *ctx);
 GSF_API int gsf_synchronize(gsf_ctx *ctx);
+/* Workspaces.  A context owns grow-only device arenas that are kept between calls (no call pays hipMalloc / hipFree once they have
+   grown): the kernel workspace (time alignment slabs, the transposed copy of a small time-major batch: 145 B/pose; the robust chain:
+   ~54 B/pose + 4 B x max_trials x min_samples per trajectory), the staging arena + pinned mirror of the host-pointer entry points
+   (the size of the largest call, up to 32 MB pinned), the float rows of the K2b screen (28 B per row + 25 %) and -- chosen
+   automatically for <= 16 MT19937 streams of <= 2 040 rows -- the tape and transition tables of the chip-wide draws (up to 768 MB,
+   960 MB with the growth margin; a few MB at the reference's own shape of one stream of 271 rows).  gsf_trim synchronises the stream
+   and releases all of them (they grow again on demand); call it before sizing a large allocation to what the device has free. */
+GSF_API int gsf_trim(gsf_ctx *ctx);
 /* tuning knobs; keys:
      "duo_kernel"     -1 automatic (default) / 0 never / 1 always: two-wave build of the fused pipeline for small batches of short tracks
      "lane_min_traj"  time-major batches with fewer trajectories than this (default 32768) are transposed and run by the
@@ -104,10 +117,32 @@ GSF_API int gsf_synchronize(gsf_ctx *ctx);
      "tape_draws"     -1 automatic (default): up to 16 MT19937 streams of <= 2040 rows are drawn chip-wide (csrc/gsf_rng_tape.hip) /
                       0 always one wave per stream / 2 tests only (a tape cut short: the one-wave kernel must take over)
      "k2b_screen"     1 (default): the residual counts of the RANSAC hypotheses are screened in packed single precision and re-checked in
-                      double inside the rounding band (identical counts) / 0: double throughout
+                      double inside the rounding band (identical counts) / 0: double throughout.  The band carries 1e-6 m of slack for
+                      the double path's own rounding, which covers coordinates up to ~1e9 m in magnitude (UTM: 1e7); rows beyond
+                      that should be fitted with the screen off
      "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift
      "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
+/* Which rows feed the Sim3 fit of the fused chains (gsf_fuse_pipeline_*, gsf_fuse_pipeline_robust_*) on this context from now on.
+     mode 0 (default)  every row with valid, finite GNSS (the operator SURVEY 8(b)/(d) defined for the batch configs)
+     mode 1            what main_process_gui does between its alignment and its fit (EKFGPSSLAM.py:973-998): of the valid rows V (in row
+                       order), the rows before the first k with ts[V[k+1]] - ts[V[k]] > max_gps_gap_threshold -- V[k] itself is left out,
+                       :981-982 -- or all of V when there is no such k; if those are fewer than min_samples: all of V (:984-986); else
+                       the rows of that segment with ts <= ts[V[0]] + max_initial_duration, or the whole segment when fewer than
+                       min_samples of them remain (:988-996).  Fewer than min_samples valid rows: the reference raises ValueError
+                       (:975, :997) -> GSF_SIM3_NONE | GSF_SIM3_FLAG_FEW_ROWS in the status word.
+   min_samples = CONFIG['sim3_ransac']['min_samples'], the other two CONFIG['time_alignment'] / CONFIG['sim3_ransac'] values. */
+GSF_API int gsf_set_sim3_rows(gsf_ctx *ctx, int32_t mode, int32_t min_samples, double max_gps_gap_threshold, double max_initial_duration);
+/* The same choice on its own, for B trajectories of N rows (offsets == NULL) or ragged ones (rows offsets[b]..offsets[b+1], N ignored):
+   row_mask[total] = 1 on the chosen rows, n_rows[b] their number (-1 where the reference raises ValueError), status[b] (may be NULL) the
+   GSF_SIM3_FLAG_FEW_ROWS / _ROWS_ALL / _ROWS_SEGMENT bit.  A row is "valid" when valid[i] != 0 and -- if gps != NULL -- its fix is
+   free of NaN (what the fused chains use).  Device pointers, asynchronous. */
+GSF_API int gsf_sim3_fit_rows_batch_dev(gsf_ctx *ctx, const double *ts, const double *gps, const uint8_t *valid, const int64_t *offsets,
+                                        int64_t B, int64_t N, int32_t min_samples, double max_gps_gap_threshold,
+                                        double max_initial_duration, uint8_t *row_mask, int32_t *n_rows, int32_t *status);
+GSF_API int gsf_sim3_fit_rows_batch(gsf_ctx *ctx, const double *ts, const double *gps, const uint8_t *valid, const int64_t *offsets,
+                                    int64_t B, int64_t N, int32_t min_samples, double max_gps_gap_threshold, double max_initial_duration,
+                                    uint8_t *row_mask, int32_t *n_rows, int32_t *status);                     /* host arrays */
 /* opens / closes a HIP-event bracket on the context's stream; gsf_timer_stop returns the elapsed ms */
 GSF_API int gsf_timer_start(gsf_ctx *ctx);
 GSF_API int gsf_timer_stop(gsf_ctx *ctx, float *elapsed_ms);
@@ -271,8 +306,9 @@ GSF_API int gsf_ekf_fuse_batch(gsf_ctx *ctx, int32_t layout, const double *ts, c
                        const gsf_ekf_config *cfg, int64_t B, int64_t N, double *pos_out, double *quat_out,
                        int32_t *status);
 
-/* ---- fused pipeline: Umeyama on the valid rows -> Sim3 of pose 0 -> EKF+RTS, one launch chain --------- */
-/* (steps 3-5 of main_process_gui, EKFGPSSLAM.py:1002-1010, with the plain fit of :428 instead of RANSAC).
+/* ---- fused pipeline: Umeyama on the chosen rows -> Sim3 of pose 0 -> EKF+RTS, one launch chain --------- */
+/* (steps 3-5 of main_process_gui, EKFGPSSLAM.py:1002-1010, with the plain fit of :428 instead of RANSAC; the rows of the fit are
+   every valid row or the reference's choice of :973-998 -- gsf_set_sim3_rows).
    Trajectories whose fit is None get status GSF_ST_* | (GSF_SIM3_NONE << 8) and NaN outputs. */
 GSF_API int gsf_fuse_pipeline_batch_dev(gsf_ctx *ctx, int32_t layout, const double *ts, const double *pos, const double *quat,
                                 const double *gps, const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N,
@@ -282,7 +318,8 @@ GSF_API int gsf_fuse_pipeline_batch(gsf_ctx *ctx, int32_t layout, const double *
                             double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status);   /* host arrays */
 
 /* ---- the same steps with the reference's ROBUST fit (compute_sim3_transform_robust, EKFGPSSLAM.py:1002, :389-426) ---------- */
-/* One device chain, no host round trip: rows with valid finite GNSS -> max_trials hypotheses drawn from each trajectory's
+/* One device chain, no host round trip: rows with valid finite GNSS (all of them, or the reference's choice of :973-998:
+   gsf_set_sim3_rows) -> max_trials hypotheses drawn from each trajectory's
    legacy MT19937 stream (mt_state[B][625], in/out: see gsf_mt19937_*) -> first-best inlier set, final Umeyama on the inliers ->
    Sim3 of pose 0 -> EKF+RTS.  Trajectory-major layout.  Outputs as gsf_fuse_pipeline_batch_dev plus n_inliers[B] (best count,
    -1 if no hypothesis succeeded) and inlier_mask[B][N] (uint8, original row order, may be NULL).  The workspace (about

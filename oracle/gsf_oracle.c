@@ -793,36 +793,89 @@ ORC_API void orc_fuse_batch(const double *ts, const double *pos, const double *q
 }
 
 
+/* Which time-synchronised rows feed the global Sim3: main_process_gui, ref :973-998.
+ * valid[i] != 0 marks the rows of valid_indices_all_sim3 (:973).  idx receives the chosen row indices (room for n), *branch
+ * 0 = the timed subset (:996), 1 = the whole first segment (:993-995), 2 = all valid rows (:984-986).
+ * Returns the number of rows, or -1 where the reference raises ValueError (:975, :997). */
+ORC_API int64_t orc_pick_sim3_rows(const double *ts, const uint8_t *valid, int64_t n, int min_samples, double max_gap,
+                                   double max_dur, int64_t *idx, int *branch)
+{
+    int64_t *vi = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    int64_t nv = 0, m = 0;
+    if (branch) *branch = 2;
+    for (int64_t i = 0; i < n; ++i) if (valid[i]) vi[nv++] = i;                      /* :973 np.where */
+    if (nv < min_samples) { free(vi); return -1; }                                   /* :974-975 */
+    if (nv > 0) {                                                                    /* :978 */
+        int64_t end = nv;                                                            /* :981 no gap: len(valid_indices) */
+        for (int64_t k = 0; k + 1 < nv; ++k)                                         /* :979-980 np.diff > threshold, first hit */
+            if (ts[vi[k + 1]] - ts[vi[k]] > max_gap) { end = k; break; }             /* :981 first_gap_idx[0] -- NOT k + 1 */
+        if (end < min_samples) {                                                     /* :983 first segment too short */
+            for (int64_t k = 0; k < nv; ++k) idx[m++] = vi[k];                       /* :984 all valid rows */
+            if (branch) *branch = 2;
+        } else {
+            const double t_lim = ts[vi[0]] + max_dur;                                /* :988-989 */
+            int64_t nt = 0;
+            for (int64_t k = 0; k < end; ++k) if (ts[vi[k]] <= t_lim) ++nt;          /* :990-992 */
+            if (nt < min_samples) {                                                  /* :993-995 */
+                for (int64_t k = 0; k < end; ++k) idx[m++] = vi[k];
+                if (branch) *branch = 1;
+            } else {
+                for (int64_t k = 0; k < end; ++k) if (ts[vi[k]] <= t_lim) idx[m++] = vi[k];   /* :996 */
+                if (branch) *branch = 0;
+            }
+        }
+    }
+    free(vi);
+    if (m < min_samples) return -1;                                                  /* :997 */
+    return m;
+}
+
 /* Steps 3-5 of main_process_gui (ref :1002-1010) with the plain fit of :428 for B equal-length trajectories:
- * compute_sim3_transform on the rows with valid, non-NaN GNSS -> transform_trajectory (only row 0 is consumed,
- * SURVEY Q3) -> apply_ekf_correction.  status = ekf bits | (sim3 status << 8); a None fit leaves NaN outputs. */
-ORC_API void orc_fuse_pipeline_batch(const double *ts, const double *pos, const double *quat, const double *aligned,
-                                     const uint8_t *valid, int64_t B, int64_t n, const orc_config *cfg, double *Rout,
-                                     double *tout, double *sout, double *pos_out, double *quat_out, int32_t *status)
+ * compute_sim3_transform on the chosen rows -> transform_trajectory (only row 0 is consumed) ->
+ * apply_ekf_correction.  fit_rows 0: every row with valid, non-NaN GNSS; 1: the reference's choice among those rows
+ * (orc_pick_sim3_rows, ref :973-998).  status = ekf bits | (sim3 status << 8); a None fit leaves NaN outputs; where the
+ * reference raises ValueError (:975, :997) the sim3 status is ORC_SIM3_NONE | ORC_SIM3_FLAG_FEW_ROWS. */
+#define ORC_SIM3_FLAG_FEW_ROWS 32
+#define ORC_SIM3_FLAG_ROWS_ALL 64
+#define ORC_SIM3_FLAG_ROWS_SEGMENT 128
+ORC_API void orc_fuse_pipeline_rows_batch(const double *ts, const double *pos, const double *quat, const double *aligned,
+                                          const uint8_t *valid, int64_t B, int64_t n, const orc_config *cfg, int fit_rows,
+                                          int min_samples, double max_gap, double max_dur, double *Rout, double *tout,
+                                          double *sout, double *pos_out, double *quat_out, int32_t *status, int32_t *n_rows)
 {
     double *src = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
     double *dst = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    uint8_t *ok = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
     for (int64_t b = 0; b < B; ++b) {
         const double *p = pos + b * n * 3, *z = aligned + b * n * 3, *q = quat + b * n * 4;
         const uint8_t *v = valid + b * n;
         int64_t m = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            if (!v[i] || isnan(z[i * 3]) || isnan(z[i * 3 + 1]) || isnan(z[i * 3 + 2])) continue;
-            for (int c = 0; c < 3; ++c) { src[m * 3 + c] = p[i * 3 + c]; dst[m * 3 + c] = z[i * 3 + c]; }
-            ++m;
+        int rows_flag = 0;
+        for (int64_t i = 0; i < n; ++i) ok[i] = (uint8_t)(v[i] && !(isnan(z[i * 3]) || isnan(z[i * 3 + 1]) || isnan(z[i * 3 + 2])));
+        if (fit_rows) {
+            int br = 0;
+            m = orc_pick_sim3_rows(ts + b * n, ok, n, min_samples, max_gap, max_dur, idx, &br);
+            rows_flag = m < 0 ? ORC_SIM3_FLAG_FEW_ROWS : (br == 2 ? ORC_SIM3_FLAG_ROWS_ALL : (br == 1 ? ORC_SIM3_FLAG_ROWS_SEGMENT : 0));
+        } else {
+            for (int64_t i = 0; i < n; ++i) if (ok[i]) idx[m++] = i;
         }
+        if (n_rows) n_rows[b] = (int32_t)m;
+        for (int64_t k = 0; k < m; ++k)
+            for (int c = 0; c < 3; ++c) { src[k * 3 + c] = p[idx[k] * 3 + c]; dst[k * 3 + c] = z[idx[k] * 3 + c]; }
         double R[9], t[3], s = NAN;
-        int fit = orc_umeyama(src, dst, m, R, t, &s);
+        int fit = m < 0 ? ORC_SIM3_NONE : orc_umeyama(src, dst, m, R, t, &s);
+        fit |= rows_flag;
         double p0[3], q0[4];
         int bad = 1;
-        if (fit != ORC_SIM3_NONE && n > 0) bad = orc_transform_trajectory(p, q, 1, R, t, s, p0, q0);
-        if (fit == ORC_SIM3_NONE || bad) {
+        if (!(fit & ORC_SIM3_NONE) && n > 0) bad = orc_transform_trajectory(p, q, 1, R, t, s, p0, q0);
+        if ((fit & ORC_SIM3_NONE) || bad) {
             for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = NAN;
             for (int k = 0; k < 3; ++k) tout[b * 3 + k] = NAN;
             sout[b] = NAN;
             for (int64_t i = 0; i < n * 3; ++i) pos_out[b * n * 3 + i] = NAN;
             for (int64_t i = 0; i < n * 4; ++i) quat_out[b * n * 4 + i] = NAN;
-            if (status) status[b] = (fit == ORC_SIM3_NONE ? (ORC_SIM3_NONE << 8) : 0) | (bad && fit != ORC_SIM3_NONE ? ORC_ST_BAD_QUAT : 0);
+            if (status) status[b] = ((fit & ORC_SIM3_NONE) ? ((ORC_SIM3_NONE | (fit & ORC_SIM3_FLAG_FEW_ROWS)) << 8) : 0) | (bad && !(fit & ORC_SIM3_NONE) ? ORC_ST_BAD_QUAT : 0);
             continue;
         }
         for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = R[k];
@@ -831,7 +884,15 @@ ORC_API void orc_fuse_pipeline_batch(const double *ts, const double *pos, const 
         int st = orc_apply_ekf_correction(ts + b * n, p, q, z, v, n, p0, q0, cfg, pos_out + b * n * 3, quat_out + b * n * 4);
         if (status) status[b] = st | (fit << 8);
     }
-    free(src); free(dst);
+    free(src); free(dst); free(ok); free(idx);
+}
+
+/* the same on every row with valid, non-NaN GNSS (fit_rows = 0): the operator SURVEY 8(b)/(d) defined for the batch configs */
+ORC_API void orc_fuse_pipeline_batch(const double *ts, const double *pos, const double *quat, const double *aligned,
+                                     const uint8_t *valid, int64_t B, int64_t n, const orc_config *cfg, double *Rout,
+                                     double *tout, double *sout, double *pos_out, double *quat_out, int32_t *status)
+{
+    orc_fuse_pipeline_rows_batch(ts, pos, quat, aligned, valid, B, n, cfg, 0, 0, 0.0, 0.0, Rout, tout, sout, pos_out, quat_out, status, NULL);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -111,6 +111,12 @@ def lib():
         L.orc_fuse_pipeline_batch.restype = None
         L.orc_fuse_pipeline_batch.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, C.c_int64, C.POINTER(OrcConfig),
                                               f64p, f64p, f64p, f64p, f64p, i32p]
+        L.orc_pick_sim3_rows.restype = C.c_int64
+        L.orc_pick_sim3_rows.argtypes = [f64p, u8p, C.c_int64, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"),
+                                         C.POINTER(C.c_int)]
+        L.orc_fuse_pipeline_rows_batch.restype = None
+        L.orc_fuse_pipeline_rows_batch.argtypes = [f64p, f64p, f64p, f64p, u8p, C.c_int64, C.c_int64, C.POINTER(OrcConfig), C.c_int, C.c_int,
+                                                   C.c_double, C.c_double, f64p, f64p, f64p, f64p, f64p, i32p, i32p]
         L.orc_estimate_time_offset.restype = C.c_double
         L.orc_estimate_time_offset.argtypes = [f64p, C.c_int64, f64p, C.c_int64, C.c_int]
         L.orc_dynamic_time_alignment.restype = None
@@ -286,17 +292,52 @@ def fuse_batch(ts, pos, quat, aligned, valid, init_pos, init_quat, cfg=None):
     return po, qo, st
 
 
-def fuse_pipeline_batch(ts, pos, quat, aligned, valid, cfg=None):
-    """Umeyama(valid rows) -> Sim3 of pose 0 -> EKF+RTS for B equal-length trajectories (trajectory-major AoS).
-    Returns pos (B,n,3), quat (B,n,4), status (B,), R (B,9), t (B,3), s (B,)."""
+def _rows_rule(cfg, fit_rows):
+    """(mode, min_samples, max_gap, max_dur) of the reference's CONFIG (EKFGPSSLAM.py:34, :53, :37) or of the dict `cfg`"""
+    if fit_rows in ("all", 0, False, None):
+        return 0, 0, 0.0, 0.0
+    if fit_rows not in ("reference", 1, True):
+        raise ValueError(f"fit_rows must be 'reference' or 'all', got {fit_rows!r}")
+    r, t = (cfg or {}).get("sim3_ransac", {}), (cfg or {}).get("time_alignment", {})
+    return 1, int(r.get("min_samples", 4)), float(t.get("max_gps_gap_threshold", 5.0)), float(r.get("max_initial_duration", 180.0))
+
+
+def fuse_pipeline_batch(ts, pos, quat, aligned, valid, cfg=None, fit_rows="reference", return_rows=False):
+    """Umeyama -> Sim3 of pose 0 -> EKF+RTS for B equal-length trajectories (trajectory-major AoS).  fit_rows="reference": the fit
+    sees the rows main_process_gui picks (EKFGPSSLAM.py:973-998); "all": every valid row.
+    Returns pos (B,n,3), quat (B,n,4), status (B,), R (B,9), t (B,3), s (B,) [, n_rows (B,)]."""
+    mode, ms, gap, dur = _rows_rule(cfg, fit_rows)
+    out = fuse_pipeline_rows_batch(ts, pos, quat, aligned, valid, cfg, mode, ms, gap, dur)
+    return out if return_rows else out[:6]
+
+
+# status bits of the Sim3 row choice (fit status << 8 in the fused status word)
+SIM3_FLAG_FEW_ROWS, SIM3_FLAG_ROWS_ALL, SIM3_FLAG_ROWS_SEGMENT = 32, 64, 128
+
+
+def pick_sim3_rows(ts, valid, min_samples=4, max_gap=5.0, max_dur=180.0, return_branch=False):
+    """Which time-synchronised rows feed the global Sim3 (main_process_gui, EKFGPSSLAM.py:973-998).  Returns the row indices, or
+    None where the reference raises ValueError (:975, :997); branch 0 timed subset / 1 whole first segment / 2 all valid rows."""
+    ts = _a(ts).ravel()
+    valid = np.ascontiguousarray(valid, dtype=np.uint8).ravel()
+    idx, br = np.empty(max(ts.size, 1), dtype=np.int64), C.c_int()
+    m = lib().orc_pick_sim3_rows(ts, valid, ts.size, int(min_samples), float(max_gap), float(max_dur), idx, C.byref(br))
+    out = None if m < 0 else idx[:m].copy()
+    return (out, br.value) if return_branch else out
+
+
+def fuse_pipeline_rows_batch(ts, pos, quat, aligned, valid, cfg=None, fit_rows=1, min_samples=4, max_gap=5.0, max_dur=180.0):
+    """fuse_pipeline_batch with the rows of the fit chosen as main_process_gui chooses them (fit_rows=1, EKFGPSSLAM.py:973-998) or all
+    valid rows (fit_rows=0).  Returns pos, quat, status, R, t, s, n_rows (B,) (-1 where the reference raises ValueError)."""
     ts, pos, quat, aligned = _a(ts), _a(pos), _a(quat), _a(aligned)
     valid = np.ascontiguousarray(valid, dtype=np.uint8)
     B, n = ts.shape
     po, qo = np.empty((B, n, 3)), np.empty((B, n, 4))
-    R, t, s, st = np.empty((B, 9)), np.empty((B, 3)), np.empty(B), np.zeros(B, dtype=np.int32)
+    R, t, s, st, nr = np.empty((B, 9)), np.empty((B, 3)), np.empty(B), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
     c = OrcConfig.from_dict(cfg)
-    lib().orc_fuse_pipeline_batch(ts, pos, quat, aligned, valid, B, n, C.byref(c), R, t, s, po, qo, st)
-    return po, qo, st, R, t, s
+    lib().orc_fuse_pipeline_rows_batch(ts, pos, quat, aligned, valid, B, n, C.byref(c), int(fit_rows), int(min_samples), float(max_gap),
+                                       float(max_dur), R, t, s, po, qo, st, nr)
+    return po, qo, st, R, t, s, nr
 
 
 def evaluate_trajectory_errors(ts, traj_pos, aligned, valid, skip_seconds=5.0):

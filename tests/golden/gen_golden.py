@@ -625,11 +625,141 @@ def gen_step6_with_ground_truth(slam):
     print(f"   step 6: GT zone {zone}{hemi!r}, {len(out['post_idx_gt'])} GT points / {len(out['post_idx_primary'])} primary points, plot ref {out['plot_ref']}")
 
 
+# --------------------------------------------------------------------------
+class HeadlessGui:
+    """Runs the reference's OWN main_process_gui (ref :940-1123) without a display: the tk dialogs, the two file loaders and the
+    plot are replaced on the imported module; everything between them -- the time alignment of step 2, the Sim3 row selection
+    :973-998, the robust fit :1002, steps 4-5 -- is the reference's code, and what it hands from step to step is recorded."""
+
+    def __init__(self, slam, gps):
+        self.slam, self.gps, self.rec = slam, gps, {}
+
+    def run(self, seed):
+        names = ("select_slam_file", "select_gps_file", "load_slam_trajectory", "load_gps_data", "plot_results",
+                 "compute_sim3_transform_robust", "transform_trajectory", "apply_ekf_correction")
+        saved = {k: getattr(ref, k) for k in names}
+        rec = self.rec
+        ref.select_slam_file = lambda: "slam.txt"
+        ref.select_gps_file = lambda *a, **k: "gps.txt"
+        ref.load_slam_trajectory = lambda path: {k: v.copy() for k, v in self.slam.items()}
+        ref.load_gps_data = lambda path, data_label="GPS", filter_config_override=None: {k: (None if v is None else v.copy()) for k, v in self.gps.items()}
+        ref.plot_results = lambda *a, **k: None
+        ref.messagebox.askyesno = lambda *a, **k: False
+        ref.messagebox.showerror = lambda title, msg: rec.__setitem__("error", str(msg).splitlines()[0])
+
+        def robust(src, dst, *a, **k):
+            rec["src"], rec["dst"] = np.array(src), np.array(dst)
+            out = saved["compute_sim3_transform_robust"](src, dst, *a, **k)
+            rec["fit"] = out
+            return out
+
+        def transform(*a, **k):
+            out = saved["transform_trajectory"](*a, **k)
+            rec["sim3_pos"], rec["sim3_quat"] = np.array(out[0]), np.array(out[1])
+            return out
+
+        def ekf(*a, **k):
+            with AlignRecorder() as ar:
+                out = saved["apply_ekf_correction"](*a, **k)
+            rec["ekf_aligned"], rec["ekf_valid"] = ar.calls[0]
+            rec["ekf_pos"], rec["ekf_quat"] = np.array(out[0]), np.array(out[1])
+            return out
+        ref.compute_sim3_transform_robust, ref.transform_trajectory, ref.apply_ekf_correction = robust, transform, ekf
+        np.random.seed(seed)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()), AlignRecorder() as ar:
+                ref.main_process_gui()
+            if ar.calls:
+                rec["aligned"], rec["valid"] = ar.calls[0]                   # step 2's alignment (ref :971)
+        finally:
+            for k, v in saved.items():
+                setattr(ref, k, v)
+        rec["stdout"] = buf.getvalue()
+        return rec
+
+
+def gen_sim3_rows_cases():
+    """Which time-synchronised rows feed the global Sim3 (ref :973-998) -- decided by the reference's own main_process_gui, run
+    headless (HeadlessGui) on crafted SLAM / GNSS pairs; plus what steps 3-5 make of them (seeded draws).  The rows are recovered
+    from the (src, dst) arrays main_process_gui hands to compute_sim3_transform_robust (SLAM positions are unique)."""
+    rng = np.random.default_rng(973)
+    out, names = {}, []
+    sec = ("time_alignment", "sim3_ransac")
+    base = {k: dict(ref.CONFIG[k]) for k in sec}
+
+    def add(name, ts, pos, quat, gps_rows, seed, max_dur=None, gap=None, min_samples=None, gps_t=None, gps_p=None):
+        for k in sec:
+            ref.CONFIG[k].clear(); ref.CONFIG[k].update(base[k])
+        if max_dur is not None: ref.CONFIG["sim3_ransac"]["max_initial_duration"] = max_dur
+        if gap is not None: ref.CONFIG["time_alignment"]["max_gps_gap_threshold"] = gap
+        if min_samples is not None: ref.CONFIG["sim3_ransac"]["min_samples"] = min_samples
+        slam = {"timestamps": ts, "positions": pos, "quaternions": quat}
+        gps = {"timestamps": gps_t[gps_rows], "positions": gps_p[gps_rows], "projector": None}
+        r = HeadlessGui(slam, gps).run(seed)
+        failed = "src" not in r
+        idx = np.empty(0, np.int32)
+        if not failed:
+            idx = np.array([int(np.where((pos == row).all(axis=1))[0][0]) for row in r["src"]], dtype=np.int32)
+            assert np.array_equal(r["dst"], r["aligned"][idx])
+        # which branch of :982-996 the reference took, read off its own printed description (:999)
+        so = r["stdout"]
+        branch = 2 if "第一段太短" in so else (1 if "移除了时间阈值" in so else 0)
+        o = dict(ts=ts, pos=pos, quat=quat, gps_t=gps["timestamps"], gps_p=gps["positions"], seed=np.int64(seed),
+                 par=np.array([ref.CONFIG["time_alignment"]["max_gps_gap_threshold"], ref.CONFIG["sim3_ransac"]["max_initial_duration"],
+                               ref.CONFIG["sim3_ransac"]["min_samples"]], dtype=np.float64),
+                 aligned=r.get("aligned", np.empty((0, 3))), valid=r.get("valid", np.empty(0, bool)), sim3_idx=idx,
+                 branch=np.int32(branch), failed=np.bool_(failed), error=np.array(r.get("error", "")))
+        fit_none = failed or r["fit"][0] is None
+        o["fit_none"] = np.bool_(fit_none)
+        if not fit_none:
+            o.update(R=r["fit"][0], t=r["fit"][1], s=np.float64(r["fit"][2]), sim3_pos0=r["sim3_pos"][0], sim3_quat0=r["sim3_quat"][0],
+                     ekf_pos=r["ekf_pos"], ekf_quat=r["ekf_quat"], ekf_aligned=r["ekf_aligned"], ekf_valid=r["ekf_valid"])
+        for k, v in o.items():
+            out[f"{name}_{k}"] = v
+        names.append(name)
+        print(f"   {name}: valid {int(np.sum(o['valid']))}/{len(ts)} -> {len(idx)} rows, branch {branch}, failed {failed}"
+              + ("" if failed else f", rows {idx[0]}..{idx[-1]}") + (f" [{o['error']}]" if failed else ""))
+
+    n = 300
+    ts, pos, quat, gps, _, _ = synth_traj(rng, n)
+    allr = np.arange(n)
+    keep = lambda *cut: np.setdiff1d(allr, np.concatenate([np.arange(a, b) for a, b in cut]))
+    kw = dict(gps_t=ts, gps_p=gps)
+    add("all_valid", ts, pos, quat, allr, 1, **kw)
+    add("gap_in_first_180s", ts, pos, quat, keep((100, 161)), 2, **kw)                 # first = vi[:99]: the row before the gap is dropped too
+    add("first_segment_3_rows", ts, pos, quat, keep((3, 61)), 3, **kw)                 # :984-986 -> all valid rows
+    add("first_segment_exactly_min", ts, pos, quat, keep((5, 70)), 4, **kw)            # vi[:4]: 4 rows == min_samples, used
+    add("starts_in_outage", ts, pos, quat, keep((0, 40)), 5, **kw)
+    add("two_gaps", ts, pos, quat, keep((80, 140), (200, 260)), 6, **kw)
+    add("timed_too_short", ts, pos, quat, keep((150, 215)), 7, max_dur=0.25, **kw)     # :993-995 -> whole first segment
+    add("short_duration_limit", ts, pos, quat, keep((150, 215)), 8, max_dur=6.0, **kw)
+    add("too_few_valid", ts, pos, quat, np.array([10, 11, 12]), 9, **kw)               # :975 ValueError
+    add("ends_in_outage", ts, pos, quat, keep((220, 300)), 10, **kw)
+    add("min_samples_6", ts, pos, quat, keep((5, 70)), 11, min_samples=6, **kw)        # first segment of 4 rows < 6 -> all valid rows
+    # a SLAM stamp that jumps ahead: a "gap" that comes from the SLAM stamps alone (np.diff of the valid rows' stamps, :979)
+    tj = ts.copy(); tj[60] += 7.0
+    add("slam_stamp_jump", tj, pos, quat, allr, 12, **kw)
+    # a stamp out of order inside the first segment: the duration limit is a per-row mask, not a prefix (:990)
+    tn = ts.copy(); tn[20] += 4.0
+    add("limit_mask_not_prefix", tn, pos, quat, allr, 13, max_dur=3.0, **kw)
+    # > 180 s: the default duration limit bites (2 000 poses = 208 s)
+    ts_l, pos_l, quat_l, gps_l, _, _ = synth_traj(rng, 2000, yaw_rate_deg=0.5)
+    add("longer_than_180s", ts_l, pos_l, quat_l, np.arange(2000), 14, gps_t=ts_l, gps_p=gps_l)
+    for k in sec:
+        ref.CONFIG[k].clear(); ref.CONFIG[k].update(base[k])
+    out["names"] = np.array(names)
+    save("sim3_rows_cases.npz", **out)
+
+
 if __name__ == "__main__":
     if "--only-step6" in sys.argv:
         with quiet():
             slam_ = ref.load_slam_trajectory(f"{REF}/yolotum04.txt")
         gen_step6_with_ground_truth(slam_)
+        sys.exit(0)
+    if "--only-sim3-rows" in sys.argv:
+        gen_sim3_rows_cases()
         sys.exit(0)
     if "--only-filter" in sys.argv:                  # later additions regenerate alone: the other files stay byte-identical
         gen_filter_cases()
@@ -643,3 +773,4 @@ if __name__ == "__main__":
     gen_align_cases(slam)
     gen_filter_cases()
     gen_step6_with_ground_truth(slam)
+    gen_sim3_rows_cases()

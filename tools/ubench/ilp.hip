@@ -122,6 +122,54 @@ __global__ void dppx_chain(double* out, long long* cyc, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
+// gfx950 only: v_permlane16_swap_b32 / v_permlane32_swap_b32 (whole 16- / 32-lane rows exchanged lane for lane) as the cross-row move of a
+// scan stage: two swaps per double + an FMA on the moved value, four independent chains -- to be compared with row_bcast:15/31 above
+template <int WIDE>
+__global__ void permswap_chain(double* out, long long* cyc, int iters)
+{
+    double x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = threadIdx.x + c;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long b = __double_as_longlong(x[c]);
+                const unsigned blo = (unsigned)b, bhi = (unsigned)(b >> 32);
+                unsigned lo, hi;
+                if (WIDE == 16) { lo = __builtin_amdgcn_permlane16_swap(blo, blo, false, false)[0]; hi = __builtin_amdgcn_permlane16_swap(bhi, bhi, false, false)[0]; }
+                else { lo = __builtin_amdgcn_permlane32_swap(blo, blo, false, false)[0]; hi = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false)[0]; }
+                x[c] = fma(x[c], 0.5, __longlong_as_double(((long long)hi << 32) | lo));
+            }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+// ds_bpermute of a double (two 32-bit LDS-crossbar moves) + FMA, four chains: the __shfl route
+__global__ void bpermute_chain(double* out, long long* cyc, int iters)
+{
+    double x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = threadIdx.x + c;
+    const int src = ((threadIdx.x & 63) ^ 16) << 2;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long b = __double_as_longlong(x[c]);
+                const int lo = __builtin_amdgcn_ds_bpermute(src, (int)b), hi = __builtin_amdgcn_ds_bpermute(src, (int)(b >> 32));
+                x[c] = fma(x[c], 0.5, __longlong_as_double(((long long)hi << 32) | (unsigned)lo));
+            }
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] + x[1] + x[2] + x[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
 // scalar ALU: dependent 64-bit mask arithmetic on a wave-uniform value (s_lshr_b64 / s_and_b64 / s_xor_b64 / s_add_u32 ...)
 __global__ void salu_chain(double* out, long long* cyc, int iters, unsigned long long seed)
 {
@@ -216,6 +264,9 @@ int main(int argc, char** argv)
     run("row_bcast:15 x2 + fma, 4 chains", dppx_chain<0x142, 0xa>, 4, 8 * 3, blocks, threads);
     run("row_bcast:31 x2 + fma, 4 chains", dppx_chain<0x143, 0xc>, 4, 8 * 3, blocks, threads);
     run("wave_shr:1 x2 + fma, 4 chains", dppx_chain<0x138, 0xf>, 4, 8 * 3, blocks, threads);
+    run("permlane16_swap x2 + fma, 4 chains", permswap_chain<16>, 4, 8 * 3, blocks, threads);
+    run("permlane32_swap x2 + fma, 4 chains", permswap_chain<32>, 4, 8 * 3, blocks, threads);
+    run("ds_bpermute x2 + fma, 4 chains", bpermute_chain, 4, 8 * 3, blocks, threads);
     run("v_rcp_f64 + add (2 instr)", trans_chain<1>, 1, 8 * 2, blocks, threads);
     run("v_rcp_f64 + add (2 instr)", trans_chain<4>, 4, 8 * 2, blocks, threads);
     run("cmp + mul + add + 2 cndmask (x4)", cmp_sel, 1, 8 * 4, blocks, threads);
