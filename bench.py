@@ -928,7 +928,7 @@ def robust_chain(torch, np, B, timed, dev, nb, N, fit_rows, parity=0):
         def chain():
             keep[0] = B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False, fit_rows=fit_rows)
         ms_r = timed(chain, 5)
-        npop = torch.full((nb,), N, dtype=torch.int32, device=dev)
+        npop = [N] * nb                                                    # (host values: the library then knows the largest population)
         ms_d = timed(lambda: B.mt19937_choice_batch(st0.clone(), npop, sc["max_trials"], sc["min_samples"]), 5)
         res = {"ms": ms_r, "poses_per_s": nb * N / ms_r * 1e3, "streams": nb, "max_trials": sc["max_trials"], "fit_rows": fit_rows,
                "ms_per_1000_streams": ms_r / nb * 1000, "draws_ms": ms_d, "draws_us_per_trial_step": ms_d * 1e3 / sc["max_trials"],

@@ -58,7 +58,7 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) { return (u64)uniform64((int64
 // quat_unit()'s acceptance test alone
 __device__ __forceinline__ bool quat_norm_ok(const Quat& q)
 {
-    const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const double n2 = quat_norm2(q);                                      // the same fused chain as quat_unit: the two cannot disagree at the thresholds
     return (n2 >= 1e-280) && (n2 <= 1e280);
 }
 

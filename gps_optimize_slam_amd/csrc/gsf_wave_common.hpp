@@ -375,12 +375,19 @@ __device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, cons
                                                   const double max_gap, int64_t& row_end, int& nF, bool& in_chunk)
 {
     if (m == 0ull) return false;
-    const u64 lower = m & bits(0, lane - 1);                              // valid rows of the chunk in front of this lane
-    const int pl = lower != 0ull ? 63 - __clzll((long long)lower) : 0;
-    const double tp_in = shidx(t, pl);
-    const double tp = lower != 0ull ? tp_in : rs.t_prev;
-    const bool gp = ok && (lower != 0ull || rs.have_prev) && (t - tp > max_gap);
-    const u64 g = __ballot(gp);
+    u64 g;
+    if ((m & (m + 1ull)) == 0ull) {
+        // the usual chunk: its valid rows are lanes 0..k-1, so the previous valid row is the previous lane (lane 0: the carried row) --
+        // one DPP move instead of a per-lane bit search and a ds_bpermute round trip on the lone wave's critical path
+        const double tp = prev_lane(rs.t_prev, t);
+        g = __ballot(ok && (lane > 0 || rs.have_prev) && (t - tp > max_gap));
+    } else {
+        const u64 lower = m & bits(0, lane - 1);                          // valid rows of the chunk in front of this lane
+        const int pl = lower != 0ull ? 63 - __clzll((long long)lower) : 0;
+        const double tp_in = shidx(t, pl);
+        const double tp = lower != 0ull ? tp_in : rs.t_prev;
+        g = __ballot(ok && (lower != 0ull || rs.have_prev) && (t - tp > max_gap));
+    }
     if (g != 0ull) {
         const int gl = __ffsll((long long)g) - 1;
         const u64 lg = m & bits(0, gl - 1);

@@ -533,6 +533,31 @@ def test_bench_two_ranks_self_spawned():
     assert abs(d["value"] - 2 * d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
 
 
+def test_bench_five_ranks_rehearsal_chunked_c5_leg():
+    """More ranks than two on the one-GPU box (five: with the test process itself that is the six processes the box admits on the card):
+    `bench.py --gpus 5` starts its ranks, every rank fuses its own id block with the real kernels, the collect and the chunked C5-shaped
+    leg (4 chunks per pass, double-buffered receive, checksum sink, watchdog bookkeeping) run over gloo with CPU staging; one JSON line,
+    gathered blocks equal every rank's checksum, the gate holds.  (The RCCL legs -- ncclAllGather and the rotated direct exchange of
+    gsf_comm.hip -- need one GPU per rank and stay unmeasured until an 8-GPU node runs the same command.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--traj-per-gpu", "512", "--chunk-traj", "128"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 5 and d["config"]["trajectories_per_gpu"] == 512 and d["backend"] == "gloo"
+    assert d["collect"]["gathered_blocks_equal_rank_checksums"] is True
+    assert d["max_abs_pos_err_m"] < 1e-6 and d["status_bits_equal"] is True
+    c5 = d["c5"]
+    assert "error" not in c5 and "stalled_leg" not in c5, c5
+    assert c5["chunks"] >= 2 and c5["trajectories_per_gpu"] == 512 and c5["chunk_trajectories"] == 128
+    assert c5["collect"]["torch_all_gather"]["gathered_checksum_equals_sum_of_rank_checksums"] is True
+    assert abs(d["value"] - 5 * 512 * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
 def test_bench_two_ranks_stalled_collect_leg_exits_nonzero():
     """A collect leg that hangs (injected: every leg sleeps 6 s under a 1.5 s watchdog) ends the run with a NON-ZERO exit code, and
     rank 0 still prints one JSON line that names the stalled leg."""
@@ -952,6 +977,31 @@ def _random_outage_batch(nb, N, seed):
     init_pos += np.array([4.5e5, 5.4e6, 110.0]) * np.isnan(gps[:, 0]).any(axis=1, keepdims=True)
     init_quat = quat[:, 0] / np.linalg.norm(quat[:, 0], axis=1, keepdims=True)
     return ts, pos, quat, gps, valid, init_pos, init_quat
+
+
+@pytest.mark.parametrize("N", [257, 1000, 1025])
+def test_big_batch_build_outage_stress_vs_oracle(B, orc, N):
+    """The big-batch build of the wave kernel (ekf_wave_big_kernel, gsf_ekf_wave_big.hip: B > 2 048 -- slab loads / stores through LDS,
+    its own translation unit and scheduler; the kernel behind the C3 and C5 figures) DIRECTLY against the oracle, not through its
+    bit-equality with the small build: 4 096 outage-stress tracks per length, K4 with the default noise and the fused pipeline under
+    both row rules.  Status words exact, positions inside the gate."""
+    nb = 4096
+    ts, pos, quat, gps, valid, ip, iq = _random_outage_batch(nb, N, 4000 + N)
+    batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=0)
+    po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
+    p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
+    bad = np.nonzero(st != sto)[0]
+    assert len(bad) == 0, (N, bad[:8].tolist())
+    assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL, (N, np.abs(p - po).max())
+    for rows in ("reference", "all"):
+        pr, qr, str_, Rr, tr, sr = orc.fuse_pipeline_batch(ts, pos, quat, gps, valid, fit_rows=rows)
+        ok = np.isfinite(pr).all(axis=(1, 2))
+        out, R, t, s = B.fuse_pipeline_batch(batch, fit_rows=rows)
+        p, q, st = out.host_traj_major()
+        assert (np.isfinite(p).all(axis=(1, 2)) == ok).all(), (N, rows)
+        assert ((st & ~(16 << 8)) == str_).all(), (N, rows, np.nonzero((st & ~(16 << 8)) != str_)[0][:8].tolist())
+        assert np.abs(p[ok] - pr[ok]).max() < POS_TOL and np.abs(q[ok] - qr[ok]).max() < Q_TOL, (N, rows, np.abs(p[ok] - pr[ok]).max())
+        assert np.abs(s.cpu().numpy()[ok] - sr[ok]).max() < 1e-10
 
 
 @pytest.mark.parametrize("N", [300, 777, 4099])
