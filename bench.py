@@ -519,6 +519,8 @@ def worker(args):
     Bn, N = wl["B"], wl["N"]
     if args.traj_per_gpu:
         Bn = args.traj_per_gpu
+    if args.poses:
+        N = args.poses
     if rehearsal and args.workload != "c2":
         Bn = min(Bn, 8192)
     steps = args.steps if args.steps is not None else {"c2": 2000, "c3": 10, "c5": 1}[args.workload]
@@ -581,7 +583,8 @@ def worker(args):
         return
 
     # ------------------------------------------------------------------------------------------------ C2 / C3
-    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED, traj0=rank * Bn)   # this rank's shard: ids [rank*B, (rank+1)*B)
+    time_major = args.layout == "time"
+    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=B.LAYOUT_TIME_MAJOR if time_major else B.LAYOUT_TRAJ_MAJOR, seed=SEED, traj0=rank * Bn)   # this rank's shard: ids [rank*B, (rank+1)*B)
     out = B.FusedPoses(batch.layout, Bn, N, dev)
     f = dict(dtype=torch.float64, device=dev)
     import ctypes as C
@@ -661,7 +664,11 @@ def worker(args):
     # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
     pipe = args.kernel == "pipeline"
     blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024
-    if blk:
+    lane_route = time_major and Bn >= 32768 and not any(kv.replace(" ", "").startswith("lane_min_traj=") for kv in args.set_option)
+    if lane_route:
+        # lane per trajectory (gsf_ekf.hip): <LAYOUT, prefetch depth, waves per SIMD>
+        kernel_name, grid_threads = ("fuse_pipeline_kernel<1, 2, 2>" if pipe else "ekf_fuse_kernel<1, 2, 2>"), ((Bn + 63) // 64) * 64
+    elif blk:
         # the workgroup-per-trajectory kernel (opt-in): <PIPELINE, AXMODE, max threads, waves per SIMD, inlined cold blocks>
         Wv = (N + 63) // 64
         shape = "320, 5, true" if Wv <= 5 else ("512, 4, true" if Wv <= 8 else "1024, 4, false")
@@ -674,9 +681,19 @@ def worker(args):
         kernel_name = ("ekf_wave_kernel<%s, true, 1>" if Bn <= 2048 else "ekf_wave_big_kernel<%s, 1>") % ("true" if pipe else "false")
         grid_threads = Bn * 64
     wl_key = args.workload + ("" if pipe else "ekf") if not blk else args.workload + "block" + ("" if pipe else "ekf")   # section of the PMC profile
+    if pipe and args.fit_rows == "all":
+        wl_key += "all"                                                     # the same kernel fitting every valid row: its own section of the profile
+    if lane_route:
+        wl_key = args.workload + "lane" + ("" if pipe else "ekf")
+    if args.poses:
+        wl_key += f"_n{N}"                                                  # not a BASELINE configuration: never matches a committed section
+    elif args.traj_per_gpu and args.workload == "c3" and Bn == 32768:
+        wl_key = "c5chunk" + ("" if pipe else "ekf")                       # one chunk of the C5 shard: the grid the 38 launches of a pass have
     traffic, traffic_src = profiled_traffic(wl_key, kernel_name, grid_threads)
     result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
-                  config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N, "layout": "trajectory-major AoS (wave-per-trajectory scans)",
+                  config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N,
+                          "layout": ("time-major SoA (" + ("lane per trajectory" if lane_route else "transposed, then wave per trajectory") + ")") if time_major
+                          else "trajectory-major AoS (wave-per-trajectory scans)",
                           "step": args.kernel, "launch_mode": launch_mode, "parallelism": f"trajectory-sharded x{world}" + (", one RCCL all-gather of the fused poses after the K steps (inside the timed region)" if world > 1 else "")
                           + (" (gloo rehearsal on shared GPUs)" if rehearsal else "")},
                   roofline={"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -743,8 +760,16 @@ def worker(args):
         nb = len(idx)
         torch.cuda.synchronize()
         ix = torch.as_tensor(idx, device=dev)
-        hh = {k: getattr(batch, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
-        pg, qg, sg = out.pos.index_select(0, ix).cpu().numpy(), out.quat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
+        gb_ = batch.to_layout(B.LAYOUT_TRAJ_MAJOR)                          # (the gate reads trajectory-major views; a no-op for the default layout)
+        if time_major:
+            opos, oquat = torch.empty((Bn, N, 3), **f), torch.empty((Bn, N, 4), **f)
+            _lib.check(L.gsf_transpose_to_traj_major_dev(ctx.handle, p(out.pos), p(opos), Bn, N, 3, 8))
+            _lib.check(L.gsf_transpose_to_traj_major_dev(ctx.handle, p(out.quat), p(oquat), Bn, N, 4, 8))
+            torch.cuda.synchronize()
+        else:
+            opos, oquat = out.pos, out.quat
+        hh = {k: getattr(gb_, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
+        pg, qg, sg = opos.index_select(0, ix).cpu().numpy(), oquat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
         result["gate_sample"] = f"{nb} trajectories of the timed batch: ids {int(idx[0])}..{int(idx[nb // 3 - 1])}, {int(idx[nb // 3])}..{int(idx[2 * (nb // 3) - 1])}, {int(idx[2 * (nb // 3)])}..{int(idx[-1])}"
         if args.kernel == "pipeline":
             po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], fit_rows=args.fit_rows)
@@ -761,8 +786,9 @@ def worker(args):
         result["max_abs_quat_err"] = float(np.abs(qg[fin] - qo[fin]).max())
         result["status_bits_equal"] = bool(((sg & 0xff) == (sto & 0xff)).all()) and bool((np.isfinite(pg).all(axis=(1, 2)) == fin).all())
         # the reference's own error metric (Q15, EKFGPSSLAM.py:1013-1033) of both results against the synthetic GNSS
-        stats, _ = B.eval_errors_batch(batch.ts.index_select(0, ix), out.pos.index_select(0, ix).contiguous(), batch.gps.index_select(0, ix),
-                                       batch.valid.index_select(0, ix), 5.0)
+        stats, _ = B.eval_errors_batch(gb_.ts.index_select(0, ix), opos.index_select(0, ix).contiguous(), gb_.gps.index_select(0, ix),
+                                       gb_.valid.index_select(0, ix), 5.0)
+        del gb_, opos, oquat
         g_rmse = stats[:, 3].cpu().numpy()
         c_rmse = np.array([orc.evaluate_trajectory_errors(hh["ts"][b], po[b], hh["gps"][b], hh["valid"][b])["rmse"] for b in range(nb)])
         both = np.isfinite(g_rmse) & np.isfinite(c_rmse)
@@ -770,12 +796,12 @@ def worker(args):
                                          "max_abs_diff_m": float(np.abs(g_rmse[both] - c_rmse[both]).max()), "trajectories": int(both.sum()),
                                          "definition": "min distance to any candidate fix after the first 5 s, RMSE per trajectory (EKFGPSSLAM.py:1013-1033)"}
     # ---- both definitions of the fit's rows in one line: the headline above is --fit-rows; here the other one, same batch, same box
-    if args.kernel == "pipeline":
+    if args.kernel == "pipeline" and not args.no_other_rows:
         other = "all" if args.fit_rows == "reference" else "reference"
         torch.cuda.synchronize()
         st_head = out.status.clone(); R_head = R.clone()
         ctx.set_sim3_rows(other, B.CONFIG)
-        k3 = max(20, min(steps, 500))
+        k3 = max(20, min(steps, 100))                                       # few launches: the kernel trace of this command averages over them too
         for _ in range(10):
             launch()
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -800,7 +826,7 @@ def worker(args):
         ctx.set_sim3_rows(args.fit_rows, B.CONFIG)
         launch(); torch.cuda.synchronize()                                 # leave the headline definition's outputs in `out` for the extras
     # ---- extras (rank 0, N=1): PCIe-inclusive rate, the HBM-regime config, the drop-in's single-run latency
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and not time_major:
         result["extra"] = extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args)
     del batch, out
     torch.cuda.empty_cache()
@@ -1139,11 +1165,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--kernel", choices=["pipeline", "ekf"], default="pipeline", help="step = fused pipeline (default) or K4 only")
+    ap.add_argument("--layout", choices=["traj", "time"], default="traj",
+                    help="batch layout of the c2 / c3 step: trajectory-major (wave per trajectory, default) or time-major (lane per trajectory above "
+                         "32 768 tracks, else transposed and run by the wave kernel)")
     ap.add_argument("--fit-rows", choices=["reference", "all"], default="reference",
                     help="rows of the pipeline's Sim3 fit: what main_process_gui picks (EKFGPSSLAM.py:973-998, default) or every valid row")
     ap.add_argument("--traj-per-gpu", type=int, default=None, help="override the workload's trajectories per GPU (c5: default 1 250 000, sized down to what fits)")
     ap.add_argument("--chunk-traj", type=int, default=None, help="c5: trajectories per chunk (default 32 768)")
+    ap.add_argument("--poses", type=int, default=None, help="override the workload's poses per trajectory (counter studies: two track lengths 64 poses apart differ by exactly one chunk of the wave kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-rows", action="store_true", help="do not time the other --fit-rows definition after the headline (counter passes: every launch of the run is then the headline's)")
     ap.add_argument("--no-graph", action="store_true", help="time K eager launches instead of one hipGraph replay of them")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (C3 figures, PCIe-inclusive rate, C1 latency; N>1: the C5 leg)")
     ap.add_argument("--stall-seconds", type=float, default=240.0, help="N>1: watchdog per collect leg of the C5-shaped run (stall -> partial line, exit code 3)")

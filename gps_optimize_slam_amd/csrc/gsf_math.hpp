@@ -293,7 +293,12 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
     if (!(det * det > 1e-28 * nc2)) return false;                          // sigma3 < 1e-14 sigma1 (also rank <= 1, NaN)
     const bool reflect = det < 0.0;
     const double e0 = fabs(det), nc20 = nc2;                               // e0 / nc20 >= sigma3 / sigma2  (|X0|_F = 1: sigma1 <= 1)
-    if (reflect && !(e0 < 0.3 * nc20)) return false;                       // e / (1 + e^2) < 0.3: e < 0.33, e^64 < 1e-30
+    // e0 / nc20 >= e / (1 + e^2), e = sigma3 / sigma2 (equality for sigma2 << sigma1; larger for rounder clouds), so a bound on the quotient
+    // bounds e: < 0.3 -> e < 0.33 (five squarings below: e^64 < 1e-30), < 0.47 -> e < 0.70 (eight: e^512).  Beyond that the reflection
+    // direction is left to the SVD.  (Round 4: under the reference's row choice a track with a GNSS gap fits its first segment only --
+    // fewer rows, noisier small singular values -- and those tracks are the slowest of a launch already; with the 0.3 limit alone 7 of
+    // the 1 000 tracks of the bench batch took the Jacobi route there, 2 when fitting all valid rows.)
+    if (reflect && !(e0 < 0.47 * nc20)) return false;
     // The well-separated reflection direction (the usual case): the largest row of cof(X0), three steps of x <- cof^T (cof x)
     // (e^7 < 1e-17 for e < 3e-3).  Computed unconditionally and in the same straight-line code as the Newton steps below: it depends on
     // cof(X0) only, and the Newton steps are a dependent chain that leaves issue slots free (a lone wave issues a dependent FP64
@@ -341,7 +346,7 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
             for (int c = 0; c < 3; ++c) R[r * 3 + c] = X[c * 3 + r];
     } else {
         if (!(e0 < 3e-3 * nc20)) {
-            // weakly separated (e up to 0.33): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
+            // weakly separated (e up to 0.70): B = cof^T cof = sum (sigma_j sigma_k)^2 v_i v_i^T squared five times (trace-normalised), so
             // that v3 v3^T dominates by e^64; v3 is its largest column
             if (LOWREG) {
                 double X0[9];
@@ -360,6 +365,17 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
                              c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12,
                              c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
                 b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
+            }
+            if (!(e0 < 0.3 * nc20)) {                                      // e up to 0.70: three more squarings (e^512)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double rt = seed_rcp(b00 + b11 + b22);
+                    b00 *= rt; b01 *= rt; b02 *= rt; b11 *= rt; b12 *= rt; b22 *= rt;
+                    const double c00 = b00 * b00 + b01 * b01 + b02 * b02, c01 = b00 * b01 + b01 * b11 + b02 * b12,
+                                 c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12,
+                                 c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
+                    b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
+                }
             }
             const bool p1 = b11 > b00 && b11 >= b22, p2 = b22 > b00 && b22 > b11;   // the largest diagonal entry names the largest column
             v[0] = p2 ? b02 : (p1 ? b01 : b00); v[1] = p2 ? b12 : (p1 ? b11 : b01); v[2] = p2 ? b22 : (p1 ? b12 : b02);

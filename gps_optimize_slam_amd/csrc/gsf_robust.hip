@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
     };
     RowScan rs{ false, 0.0, 0, 0 };
     bool gap_found = false, have_t0 = false, carry_in_T = false;
-    int64_t row_end = n;
+    int row_end = (int)n;
     int nF = 0, nT = 0;
     double tlim = 0.0;
     for (int64_t c0 = 0; c0 < n && !gap_found; c0 += 64) {
@@ -43,10 +43,10 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
         if (m == 0ull) continue;
         if (!have_t0) { tlim = lane_bcast(t, __ffsll((long long)m) - 1) + rule.max_dur; have_t0 = true; }   // segment_start_time + max_dur (:988-990)
         bool in_chunk = false;
-        gap_found = rows_gap_in_chunk(rs, m, t, ok, lane, c0, rule.max_gap, row_end, nF, in_chunk);
+        gap_found = rows_gap_in_chunk(rs, m, t, ok, lane, (int)c0, rule.max_gap, row_end, nF, in_chunk);
         const u64 tm = __ballot(ok && t <= tlim);
         if (gap_found) {
-            if (in_chunk) nT += __popcll(tm & bits(0, (int)(row_end - c0) - 1));
+            if (in_chunk) nT += __popcll(tm & bits(0, row_end - (int)c0 - 1));
             else nT -= carry_in_T ? 1 : 0;                                // the row in front of the gap is the carried one: it was counted, and V[:k] leaves it out
         } else {
             nT += __popcll(tm);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
     int32_t flag = 0; int count = nT;
     if (nF < rule.min_samples) {                                          // :983
         if (!gap_found) { flag = SIM3_FLAG_FEW_ROWS; count = -1; }       // :975
-        else { row_end = n; use_tlim = false; flag = SIM3_FLAG_ROWS_ALL; count = -2; }   // :984 (counted in pass 2)
+        else { row_end = (int)n; use_tlim = false; flag = SIM3_FLAG_ROWS_ALL; count = -2; }   // :984 (counted in pass 2)
     } else if (nT < rule.min_samples) { use_tlim = false; flag = SIM3_FLAG_ROWS_SEGMENT; count = nF; }   // :993-995
     int total = 0;
     for (int64_t c0 = 0; c0 < n; c0 += 64) {

@@ -143,6 +143,15 @@ __device__ __forceinline__ u64 bits(int lo, int hi)
     return upto_hi & ~below_lo;
 }
 
+// Lane masks STRAIGHT from a compare (v_cmp into an SGPR pair).  __ballot(flag) of a flag the compiler already holds as a lane mask is
+// re-materialised (v_cndmask 0/1 + v_cmp_ne against exec): two vector instructions and a VALU -> SGPR hop per mask, and the moments
+// passes below are made of masks.  Ordered compares: false for NaN operands, like the C operators.
+__device__ __forceinline__ u64 mask_not_nan(const double x) { return __builtin_amdgcn_fcmp(x, x, 7); }                 // FCMP_ORD
+__device__ __forceinline__ u64 mask_le(const double a, const double b) { return __builtin_amdgcn_fcmp(a, b, 5); }     // FCMP_OLE
+__device__ __forceinline__ u64 mask_gt(const double a, const double b) { return __builtin_amdgcn_fcmp(a, b, 2); }     // FCMP_OGT
+__device__ __forceinline__ u64 mask_nonzero(const uint32_t v) { return __builtin_amdgcn_uicmp(v, 0u, 33); }          // ICMP_NE
+__device__ __forceinline__ u64 mask_first(const int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }   // lanes 0..n-1
+
 struct WaveArgs {
     const double* ts; const double* pos; const double* quat; const double* gps; const uint8_t* valid;
     const double* init_pos; const double* init_quat;
@@ -310,11 +319,11 @@ template <> struct NextChunk<true> { typedef ChunkWide type; };
 // is None or pose 0's quaternion is invalid (wave-uniform).  sums = { n, Sa[3], Sb[3], Saa, Sab[9] } per lane.
 __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64_t b, const int64_t base, const int64_t N, const int lane,
                                                   const double* sums, const double* as_, const double* bs_, const Quat& qraw0,
-                                                  Vec3& p0, Quat& q0, int32_t& fit, const int32_t rows_flag = 0)
+                                                  Vec3& p0, Quat& q0, int32_t& fit, const int32_t rows_flag = 0, const bool n_is_total = false)
 {
     double* __restrict__ pob = a.pos_out + base * 3;
     double* __restrict__ qob = a.quat_out + base * 4;
-    const double n = wave_sum(sums[0]);
+    const double n = n_is_total ? sums[0] : wave_sum(sums[0]);            // (the moments passes of wave_prelude count their rows from the ballots)
     double Rb[9], tb[3], sb = NAN;
     fit = SIM3_NONE;
     if (n >= 3.0 && !(rows_flag & SIM3_FLAG_FEW_ROWS)) {                  // ref :430 (and :975 / :997: the reference raised before it got here)
@@ -365,14 +374,14 @@ __device__ __forceinline__ bool fit_from_partials(const WaveArgs& a, const int64
 // ---- the Sim3 row choice of main_process_gui (ref :973-998) inside a wave.  The valid rows V are walked 64 at a time; what travels
 // from chunk to chunk (wave-uniform) is the last valid row seen so far -- its stamp, its index, and how many valid rows there are up
 // to and including it.
-struct RowScan { bool have_prev; double t_prev; int64_t i_prev; int nvalid; };
+struct RowScan { bool have_prev; double t_prev; int i_prev; int nvalid; };   // (row indices are 32-bit: 2^31 poses x 145 B would not fit the 288 GB of HBM)
 // One chunk of the walk: m = ballot of the valid rows of the chunk whose first row is c0, t = this lane's stamp.  A gap is a valid
 // row whose stamp exceeds the PREVIOUS VALID row's by more than max_gap (np.diff of the valid rows' stamps, :979-980).  On the first
 // gap: row_end = index of that previous valid row -- the segment is V[:k] with k the index of the diff, so the row in front of the gap
 // is left out as well (:981-982) -- nF = the number of valid rows before it, in_chunk = whether it sits in this chunk (else it is the
 // carried row).  Returns true on a gap; otherwise advances the carry.
-__device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, const double t, const bool ok, const int lane, const int64_t c0,
-                                                  const double max_gap, int64_t& row_end, int& nF, bool& in_chunk)
+__device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, const double t, const bool ok, const int lane, const int c0,
+                                                  const double max_gap, int& row_end, int& nF, bool& in_chunk)
 {
     if (m == 0ull) return false;
     u64 g;
@@ -382,6 +391,9 @@ __device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, cons
         const double tp = prev_lane(rs.t_prev, t);
         g = __ballot(ok && (lane > 0 || rs.have_prev) && (t - tp > max_gap));
     } else {
+        // (kept behind a REAL branch: left to itself the compiler computes both forms in every chunk and selects -- a per-lane bit search and two
+        // ds_bpermute round trips on the lone wave's critical path, 740 cycles per chunk by the in-kernel stamps, gpurun_out/r4k/timing.log)
+        asm volatile("" ::: "memory");
         const u64 lower = m & bits(0, lane - 1);                          // valid rows of the chunk in front of this lane
         const int pl = lower != 0ull ? 63 - __clzll((long long)lower) : 0;
         const double tp_in = shidx(t, pl);
@@ -413,7 +425,7 @@ __device__ __forceinline__ bool rows_gap_in_chunk(RowScan& rs, const u64 m, cons
 #define GSF_ROWS_ROUND 6                                                  // chunks per round of this pass (the big-batch build takes fewer: registers)
 #endif
 template <int MOM_ROUND>
-__device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, const int64_t base, const int64_t N, const int lane,
+__device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, const int64_t b, const int64_t base, const int64_t N, const int lane,
                                                            const double as0, const double as1, const double as2, double* sums, double* bs_,
                                                            int32_t& rows_flag)
 {
@@ -424,22 +436,23 @@ __device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, co
     const int ms = a.rows.min_samples;
     const double max_gap = a.rows.max_gap, max_dur = a.rows.max_dur;
     bool detect = true, use_tlim = true, gap_found = false;
-    int64_t row_end = N;
+    const int Ni = (int)N;
+    int row_end = Ni;
     int nF = 0, state = 0;                                               // state 0: the timed subset, 1: the whole first segment, 2: all valid rows
     rows_flag = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0, tlim = 0.0;
         bool have_shift = false, over = false;
-        RowScan rs{ false, 0.0, 0, 0 };
+        bool prev_row_ok = false; int i_last = -1, nvalid = 0; double t_before = 0.0;   // the gap check's carry: row c0 - 1 valid / its stamp, the last valid row so far, the valid rows so far
         int nT = 0;
-        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+        double Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
         double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int64_t c0 = 0; c0 < N && c0 < row_end; c0 += 64 * MOM_ROUND) {
+        for (int c0 = 0; c0 < Ni && c0 < row_end; c0 += 64 * MOM_ROUND) {
             double pa[MOM_ROUND][3], pz[MOM_ROUND][3], pt[MOM_ROUND]; uint32_t pv[MOM_ROUND];
 #pragma unroll
             for (int k = 0; k < MOM_ROUND; ++k) {
-                if (c0 + 64 * k < N) {                                    // wave-uniform
-                    const int64_t i = c0 + 64 * k + lane, il = i < N ? i : N - 1;
+                if (c0 + 64 * k < Ni) {                                   // wave-uniform
+                    const int i = c0 + 64 * k + lane; const int64_t il = i < Ni ? i : Ni - 1;
                     pa[k][0] = posb[il * 3]; pa[k][1] = posb[il * 3 + 1]; pa[k][2] = posb[il * 3 + 2];
                     pz[k][0] = gpsb[il * 3]; pz[k][1] = gpsb[il * 3 + 1]; pz[k][2] = gpsb[il * 3 + 2];
                     pt[k] = tsb[il]; pv[k] = valb[il];
@@ -449,14 +462,22 @@ __device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, co
             }
 #pragma unroll
             for (int k = 0; k < MOM_ROUND; ++k) asm volatile("" : "+v"(pv[k]));   // (see wave_prelude: one memory round trip per round)
-            bool ok[MOM_ROUND];
+            // validity of the round's rows as lane masks (rows of the track, mask byte set, fix free of NaN)
+            u64 mok[MOM_ROUND];
 #pragma unroll
             for (int k = 0; k < MOM_ROUND; ++k)
-                ok[k] = (c0 + 64 * k + lane < N) && pv[k] != 0 && !(isnan(pz[k][0]) || isnan(pz[k][1]) || isnan(pz[k][2]));
+                mok[k] = mask_first(Ni - (c0 + 64 * k)) & mask_nonzero(pv[k]) & mask_not_nan(pz[k][0]) & mask_not_nan(pz[k][1]) & mask_not_nan(pz[k][2]);
+            GSF_STAMP(1);                                                 // the round's rows have arrived
+            if (!have_shift && (mok[0] & 1ull) != 0ull) {                 // the usual track: its very first row of the round is valid
+                bs0 = lane_bcast(pz[0][0], 0); bs1 = lane_bcast(pz[0][1], 0); bs2 = lane_bcast(pz[0][2], 0);
+                tlim = lane_bcast(pt[0], 0) + max_dur;                    // segment_start_time + max_dur (:989-990)
+                have_shift = true;
+            }
             if (!have_shift) {                                            // the first valid row: GNSS-side shift and segment_start_time (:988)
+                asm volatile("" ::: "memory");                           // (behind a real branch: ~150 selects otherwise folded into every track)
                 u64 msel = 0ull; int ksel = -1;
 #pragma unroll
-                for (int k = MOM_ROUND - 1; k >= 0; --k) { const u64 m = __ballot(ok[k]); if (m != 0ull) { msel = m; ksel = k; } }
+                for (int k = MOM_ROUND - 1; k >= 0; --k) { if (mok[k] != 0ull) { msel = mok[k]; ksel = k; } }
                 if (ksel >= 0) {
                     double v0 = pz[0][0], v1 = pz[0][1], v2 = pz[0][2], vt = pt[0];
 #pragma unroll
@@ -468,23 +489,78 @@ __device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, co
                 }
             }
             if (detect && !gap_found) {
+                // Where can the first gap be?  Between two ADJACENT valid rows (g: the stamp of row i - 1 comes from the previous lane -- lane
+                // 0: lane 63 of the chunk before, a constant-lane read -- and its validity is the chunk's mask shifted by one), or in front of
+                // a valid row whose predecessor row is invalid, a RUN START (st).  Both sets are lane masks formed without a branch and without
+                // a chain from chunk to chunk.  The usual track -- its valid rows are one run -- has no candidate at all except the very first
+                // valid row: the round is accepted on two scalar compares.  Otherwise the candidates (one or two per outage) are visited in
+                // row order on the scalar unit; the stamp in front of a run start is the end of the run before, fetched through the scalar cache.
+                // (History, in-kernel stamps on a 271-pose track, gpurun_out/r4k .. r4q: walking every chunk with ~5 scalar branches each, the
+                // bit-search + ds_bpermute form folded into every chunk by if-conversion: 1.56 us on a clean track; a branch-free form that
+                // still carried the last valid stamp from chunk to chunk through v_readlane / s_cselect: 1.20 us -- a lone wave pays 20-40
+                // cycles for every VALU -> SGPR -> VALU hop; masks straight from the compares + this form: DESIGN.md section 5.)
+                u64 gk[MOM_ROUND], sk[MOM_ROUND]; u64 g_any = 0ull; int nst = 0; bool top = prev_row_ok; double tb = t_before;
 #pragma unroll
-                for (int k = 0; k < MOM_ROUND; ++k) {
-                    if (!gap_found && c0 + 64 * k < N) {                  // wave-uniform
-                        bool in_chunk = false;
-                        gap_found = rows_gap_in_chunk(rs, __ballot(ok[k]), pt[k], ok[k], lane, c0 + 64 * k, max_gap, row_end, nF, in_chunk);
-                        if (gap_found && !in_chunk && row_end < c0) over = true;   // the row in front of the gap was accumulated a round ago
+                for (int k = 0; k < MOM_ROUND; ++k) {                     // (chunks past the end of the track: m = 0, no effect)
+                    const u64 m = mok[k];
+                    const u64 mp = (m << 1) | (top ? 1ull : 0ull);        // row i - 1 is valid
+                    const double tp = prev_lane(tb, pt[k]);               // stamp of row i - 1
+                    tb = lane_bcast(pt[k], 63);
+                    gk[k] = mask_gt(pt[k] - tp, max_gap) & m & mp;        // rows i - 1 and i both valid, more than max_gap apart
+                    sk[k] = m & ~mp;                                      // run starts
+                    g_any |= gk[k]; nst += __popcll(sk[k]); top = (m >> 63) != 0ull;
+                }
+                // (the first valid row of the track is a run start with nothing in front of it: not a candidate.  One compare for the whole
+                // round -- the per-lane maximum of the differences -- instead of one per chunk measured 0.1-0.2 us slower, gpurun_out/r4s.)
+                if (g_any != 0ull || nst > (i_last < 0 ? 1 : 0)) {
+                    asm volatile("" ::: "memory");                       // (a real branch, not if-conversion)
+                    int e = i_last, cnt = nvalid;                      // last valid row so far, number of valid rows up to and including it
+#pragma unroll
+                    for (int k = 0; k < MOM_ROUND; ++k) {
+                        const u64 m = mok[k];
+                        if (!gap_found && m != 0ull) {                    // wave-uniform
+                            u64 cand = gk[k] | sk[k];
+                            while (cand != 0ull && !gap_found) {
+                                const int l = __ffsll((long long)cand) - 1; cand &= cand - 1ull;
+                                const u64 lower = m & mask_first(l);      // valid rows of this chunk in front of the candidate
+                                const int ep = lower != 0ull ? c0 + 64 * k + (63 - __clzll((long long)lower)) : e;   // the valid row in front of it ...
+                                const int before = lower != 0ull ? cnt + __popcll(lower) - 1 : cnt - 1;              // ... and how many valid rows precede THAT one
+                                if (ep < 0) continue;                     // the first valid row of the track
+                                bool gap = ((gk[k] >> l) & 1ull) != 0ull;
+                                if (!gap) gap = tsb[c0 + 64 * k + l] - tsb[ep] > max_gap;   // across a hole: np.diff of the valid rows' stamps (:979-980)
+                                if (gap) { gap_found = true; row_end = ep; nF = before; over = ep < c0; }            // V[:k] leaves row ep out as well (:981-982)
+                            }
+                            e = c0 + 64 * k + (63 - __clzll((long long)m)); cnt += __popcll(m);
+                        }
+                    }
+                    if (!gap_found) { i_last = e; nvalid = cnt; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MOM_ROUND; ++k) {
+                        if (mok[k] != 0ull) { i_last = c0 + 64 * k + (63 - __clzll((long long)mok[k])); nvalid += __popcll(mok[k]); }
                     }
                 }
+                prev_row_ok = top; t_before = tb;
+            }
+            GSF_STAMP(15);                                                // gap check of the round done
+            // which rows of the round are summed: valid AND in front of row_end AND inside the duration limit -- as 64-bit masks on the
+            // scalar unit (the row bound is a shift, only the limit needs a per-lane compare, and those are issued together up front), handed
+            // to the lanes as ready-made select masks; the number of rows summed is a popcount, not a per-lane counter
+            u64 mo[MOM_ROUND];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) mo[k] = use_tlim ? (mok[k] & mask_le(pt[k], tlim)) : mok[k];
+#pragma unroll
+            for (int k = 0; k < MOM_ROUND; ++k) {
+                mo[k] &= mask_first(row_end - (c0 + 64 * k));             // rows of this chunk in front of row_end
+                nT += __popcll(mo[k]);
             }
 #pragma unroll
             for (int k = 0; k < MOM_ROUND; ++k) {
-                if (c0 + 64 * k < N) {                                    // wave-uniform
-                    const bool o = ok[k] && (c0 + 64 * k + lane < row_end) && (!use_tlim || pt[k] <= tlim);
-                    nT += __popcll(__ballot(o));
+                if (mo[k] != 0ull) {                                      // wave-uniform (a track with a gap sums its first segment only)
+                    const bool o = __builtin_amdgcn_inverse_ballot_w64(mo[k]);
                     const double a0 = o ? pa[k][0] - as0 : 0.0, a1 = o ? pa[k][1] - as1 : 0.0, a2 = o ? pa[k][2] - as2 : 0.0;
                     const double b0 = o ? pz[k][0] - bs0 : 0.0, b1 = o ? pz[k][1] - bs1 : 0.0, b2 = o ? pz[k][2] - bs2 : 0.0;
-                    cnt += o ? 1.0 : 0.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
+                    Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
                     Saa += a0 * a0 + a1 * a1 + a2 * a2;
                     Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
                     Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
@@ -492,20 +568,21 @@ __device__ __forceinline__ void fit_moments_reference_rows(const WaveArgs& a, co
                 }
             }
         }
-        sums[0] = cnt; sums[1] = Sa0; sums[2] = Sa1; sums[3] = Sa2; sums[4] = Sb0; sums[5] = Sb1; sums[6] = Sb2; sums[7] = Saa;
+        sums[0] = (double)nT;                                             // (wave-uniform: the count of the rows summed, from the ballots)
+        sums[1] = Sa0; sums[2] = Sa1; sums[3] = Sa2; sums[4] = Sb0; sums[5] = Sb1; sums[6] = Sb2; sums[7] = Saa;
 #pragma unroll
         for (int k = 0; k < 9; ++k) sums[8 + k] = Sab[k];
         bs_[0] = bs0; bs_[1] = bs1; bs_[2] = bs2;
         if (detect) {
             detect = false;
-            if (!gap_found) nF = rs.nvalid;                               // no gap: the first segment is all of V (:981)
+            if (!gap_found) nF = nvalid;                                  // no gap: the first segment is all of V (:981)
             if (over) continue;                                           // once more, with the bound known from the start
         }
         // the sums now belong to exactly the rows (row_end, use_tlim) describe
         if (state == 0) {
             if (nF < ms) {                                                // :983
                 if (!gap_found) { rows_flag = SIM3_FLAG_FEW_ROWS; break; }           // V itself is that short: ValueError (:975)
-                row_end = N; use_tlim = false; state = 2; rows_flag = SIM3_FLAG_ROWS_ALL; continue;       // :984
+                row_end = Ni; use_tlim = false; state = 2; rows_flag = SIM3_FLAG_ROWS_ALL; continue;       // :984
             }
             if (nT < ms) { use_tlim = false; state = 1; rows_flag = SIM3_FLAG_ROWS_SEGMENT; continue; }   // :993-995
             break;                                                        // :996
@@ -539,71 +616,83 @@ __device__ __forceinline__ bool wave_prelude(const WaveArgs& a, const int64_t b,
         const double as0 = posb[0], as1 = posb[1], as2 = posb[2];
         const Quat qraw0{ quatb[0], quatb[1], quatb[2], quatb[3] };      // pose 0's quaternion: requested here, used after the fit
         constexpr int MOM_ROUND = 6;
+        // ONE closed form behind either moments pass (the two row rules differ in which rows they sum, not in what happens to the sums)
+        double sums[17], bs_[3]; int32_t rows_flag = 0;
+#ifdef GSF_NO_ROWS_RULE                                                    // A/B build (make norows): what the row-choice pass costs the OTHER path by being there
+        if (false) {
+#else
         if (a.rows.mode != 0) {                                           // wave-uniform: the reference's row choice (ref :973-998)
-            double sums[17], bs_[3]; int32_t rows_flag = 0;
-            fit_moments_reference_rows<GSF_ROWS_ROUND>(a, base, N, lane, as0, as1, as2, sums, bs_, rows_flag);
-            GSF_STAMP(2);
-            const double as_[3] = { as0, as1, as2 };
-            if (!fit_from_partials(a, b, base, N, lane, sums, as_, bs_, qraw0, p0, q0, fit, rows_flag)) return false;
-            p0_out = p0; q0_out = q0; fit_out = fit;
-            return true;
-        }
-        double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
-        bool have_shift = false;
-        double cnt = 0, Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
-        double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int64_t c0 = 0; c0 < N; c0 += 64 * MOM_ROUND) {
-            double pa[MOM_ROUND][3], pz[MOM_ROUND][3]; uint32_t pv[MOM_ROUND];
+#endif
+            fit_moments_reference_rows<GSF_ROWS_ROUND>(a, b, base, N, lane, as0, as1, as2, sums, bs_, rows_flag);
+        } else {
+            double bs0 = 0.0, bs1 = 0.0, bs2 = 0.0;
+            bool have_shift = false;
+            int nrows = 0;                                                // (counted from the ballots: wave-uniform)
+            double Sa0 = 0, Sa1 = 0, Sa2 = 0, Sb0 = 0, Sb1 = 0, Sb2 = 0, Saa = 0;
+            double Sab[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int64_t c0 = 0; c0 < N; c0 += 64 * MOM_ROUND) {
+                double pa[MOM_ROUND][3], pz[MOM_ROUND][3]; uint32_t pv[MOM_ROUND];
 #pragma unroll
-            for (int k = 0; k < MOM_ROUND; ++k) {
-                if (c0 + 64 * k < N) {                                    // wave-uniform
-                    const int64_t i = c0 + 64 * k + lane, il = i < N ? i : N - 1;
-                    pa[k][0] = posb[il * 3]; pa[k][1] = posb[il * 3 + 1]; pa[k][2] = posb[il * 3 + 2];
-                    pz[k][0] = gpsb[il * 3]; pz[k][1] = gpsb[il * 3 + 1]; pz[k][2] = gpsb[il * 3 + 2];
-                    pv[k] = valb[il];
-                } else {
-                    pa[k][0] = pa[k][1] = pa[k][2] = 0.0; pz[k][0] = pz[k][1] = pz[k][2] = 0.0; pv[k] = 0u;
+                for (int k = 0; k < MOM_ROUND; ++k) {
+                    if (c0 + 64 * k < N) {                                    // wave-uniform
+                        const int64_t i = c0 + 64 * k + lane, il = i < N ? i : N - 1;
+                        pa[k][0] = posb[il * 3]; pa[k][1] = posb[il * 3 + 1]; pa[k][2] = posb[il * 3 + 2];
+                        pz[k][0] = gpsb[il * 3]; pz[k][1] = gpsb[il * 3 + 1]; pz[k][2] = gpsb[il * 3 + 2];
+                        pv[k] = valb[il];
+                    } else {
+                        pa[k][0] = pa[k][1] = pa[k][2] = 0.0; pz[k][0] = pz[k][1] = pz[k][2] = 0.0; pv[k] = 0u;
+                    }
                 }
-            }
-            // the mask bytes stay opaque until every load of the round is issued: left alone, the compiler turns each byte into a lane
-            // mask right behind its load (one VGPR less) and thereby waits for memory once per 64 rows instead of once per round
+                // the mask bytes stay opaque until every load of the round is issued: left alone, the compiler turns each byte into a lane
+                // mask right behind its load (one VGPR less) and thereby waits for memory once per 64 rows instead of once per round
 #pragma unroll
-            for (int k = 0; k < MOM_ROUND; ++k) asm volatile("" : "+v"(pv[k]));
-            bool ok[MOM_ROUND];
+                for (int k = 0; k < MOM_ROUND; ++k) asm volatile("" : "+v"(pv[k]));
+                u64 mok[MOM_ROUND];                                           // validity of the round's rows as lane masks
 #pragma unroll
-            for (int k = 0; k < MOM_ROUND; ++k)
-                ok[k] = (c0 + 64 * k + lane < N) && pv[k] != 0 && !(isnan(pz[k][0]) || isnan(pz[k][1]) || isnan(pz[k][2]));
-            if (!have_shift) {                                            // wave-uniform, normally only in the first round
-                u64 msel = 0ull; int ksel = -1;
-#pragma unroll
-                for (int k = MOM_ROUND - 1; k >= 0; --k) { const u64 m = __ballot(ok[k]); if (m != 0ull) { msel = m; ksel = k; } }
-                if (ksel >= 0) {
-                    double v0 = pz[0][0], v1 = pz[0][1], v2 = pz[0][2];
-#pragma unroll
-                    for (int k = 1; k < MOM_ROUND; ++k) { const bool pick = (ksel == k); v0 = pick ? pz[k][0] : v0; v1 = pick ? pz[k][1] : v1; v2 = pick ? pz[k][2] : v2; }
-                    const int f = __ffsll((long long)msel) - 1;
-                    bs0 = lane_bcast(v0, f); bs1 = lane_bcast(v1, f); bs2 = lane_bcast(v2, f);
+                for (int k = 0; k < MOM_ROUND; ++k)
+                    mok[k] = mask_first((int)(N - (c0 + 64 * k) > 64 ? 64 : N - (c0 + 64 * k))) & mask_nonzero(pv[k]) & mask_not_nan(pz[k][0]) & mask_not_nan(pz[k][1]) &
+                             mask_not_nan(pz[k][2]);
+                GSF_STAMP(1);                                             // the round's rows have arrived
+                if (!have_shift && (mok[0] & 1ull) != 0ull) {             // the usual track: its very first row is valid
+                    bs0 = lane_bcast(pz[0][0], 0); bs1 = lane_bcast(pz[0][1], 0); bs2 = lane_bcast(pz[0][2], 0);
                     have_shift = true;
                 }
-            }
+                if (!have_shift) {                                            // wave-uniform, normally only in the first round
+                    asm volatile("" ::: "memory");                           // (behind a real branch: ~150 selects otherwise folded into every track)
+                    u64 msel = 0ull; int ksel = -1;
 #pragma unroll
-            for (int k = 0; k < MOM_ROUND; ++k) {
-                if (c0 + 64 * k < N) {                                    // wave-uniform
-                    const bool o = ok[k];
-                    const double a0 = o ? pa[k][0] - as0 : 0.0, a1 = o ? pa[k][1] - as1 : 0.0, a2 = o ? pa[k][2] - as2 : 0.0;
-                    const double b0 = o ? pz[k][0] - bs0 : 0.0, b1 = o ? pz[k][1] - bs1 : 0.0, b2 = o ? pz[k][2] - bs2 : 0.0;
-                    cnt += o ? 1.0 : 0.0; Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
-                    Saa += a0 * a0 + a1 * a1 + a2 * a2;
-                    Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
-                    Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
-                    Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
+                    for (int k = MOM_ROUND - 1; k >= 0; --k) { if (mok[k] != 0ull) { msel = mok[k]; ksel = k; } }
+                    if (ksel >= 0) {
+                        double v0 = pz[0][0], v1 = pz[0][1], v2 = pz[0][2];
+#pragma unroll
+                        for (int k = 1; k < MOM_ROUND; ++k) { const bool pick = (ksel == k); v0 = pick ? pz[k][0] : v0; v1 = pick ? pz[k][1] : v1; v2 = pick ? pz[k][2] : v2; }
+                        const int f = __ffsll((long long)msel) - 1;
+                        bs0 = lane_bcast(v0, f); bs1 = lane_bcast(v1, f); bs2 = lane_bcast(v2, f);
+                        have_shift = true;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < MOM_ROUND; ++k) {
+                    if (c0 + 64 * k < N) {                                    // wave-uniform
+                        const bool o = __builtin_amdgcn_inverse_ballot_w64(mok[k]);
+                        const double a0 = o ? pa[k][0] - as0 : 0.0, a1 = o ? pa[k][1] - as1 : 0.0, a2 = o ? pa[k][2] - as2 : 0.0;
+                        const double b0 = o ? pz[k][0] - bs0 : 0.0, b1 = o ? pz[k][1] - bs1 : 0.0, b2 = o ? pz[k][2] - bs2 : 0.0;
+                        nrows += __popcll(mok[k]); Sa0 += a0; Sa1 += a1; Sa2 += a2; Sb0 += b0; Sb1 += b1; Sb2 += b2;
+                        Saa += a0 * a0 + a1 * a1 + a2 * a2;
+                        Sab[0] += a0 * b0; Sab[1] += a0 * b1; Sab[2] += a0 * b2;
+                        Sab[3] += a1 * b0; Sab[4] += a1 * b1; Sab[5] += a1 * b2;
+                        Sab[6] += a2 * b0; Sab[7] += a2 * b1; Sab[8] += a2 * b2;
+                    }
                 }
             }
+            sums[0] = (double)nrows; sums[1] = Sa0; sums[2] = Sa1; sums[3] = Sa2; sums[4] = Sb0; sums[5] = Sb1; sums[6] = Sb2; sums[7] = Saa;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sums[8 + k] = Sab[k];
+            bs_[0] = bs0; bs_[1] = bs1; bs_[2] = bs2;
         }
         GSF_STAMP(2);
-        const double sums[17] = { cnt, Sa0, Sa1, Sa2, Sb0, Sb1, Sb2, Saa, Sab[0], Sab[1], Sab[2], Sab[3], Sab[4], Sab[5], Sab[6], Sab[7], Sab[8] };
-        const double as_[3] = { as0, as1, as2 }, bs_[3] = { bs0, bs1, bs2 };
-        if (!fit_from_partials(a, b, base, N, lane, sums, as_, bs_, qraw0, p0, q0, fit)) return false;
+        const double as_[3] = { as0, as1, as2 };
+        if (!fit_from_partials(a, b, base, N, lane, sums, as_, bs_, qraw0, p0, q0, fit, rows_flag, true)) return false;
     } else {
         p0 = Vec3{ a.init_pos[b * 3], a.init_pos[b * 3 + 1], a.init_pos[b * 3 + 2] };
         q0 = Quat{ a.init_quat[b * 4], a.init_quat[b * 4 + 1], a.init_quat[b * 4 + 2], a.init_quat[b * 4 + 3] };

@@ -150,7 +150,7 @@ def test_umeyama_polar_route(hh, golden):
             assert abs(sx - so) < 1e-12 * so
             np.testing.assert_allclose(sx * src @ Rx.T + tx, so * src @ Ro.T + to, atol=1e-8, rtol=0)
     assert n_polar > 300 and n_refl > 100                                   # the fast route is the one exercised, reflections included
-    # mirrored clouds with a controlled sigma3/sigma2 from 1e-8 to 0.7 (beyond 0.33 the route must hand over to the SVD, not guess)
+    # mirrored clouds with a controlled sigma3/sigma2 from 1e-4 to 0.83 (beyond 0.70 the route must hand over to the SVD, not guess)
     took = 0
     for trial in range(300):
         n = 60
@@ -164,8 +164,10 @@ def test_umeyama_polar_route(hh, golden):
         assert np.linalg.det(H) < 0
         sv = np.linalg.svd(H, compute_uv=False)
         ok = hh.hh_polar_applies(H); took += ok
-        if sv[2] / sv[1] < 0.25:
+        if sv[2] / sv[1] < 0.55:
             assert ok, (trial, sv)
+        if sv[2] / sv[1] > 0.72:
+            assert not ok, (trial, sv)
         R, t, s = np.empty((3, 3)), np.empty(3), C.c_double()
         R2, t2, s2 = np.empty((3, 3)), np.empty(3), C.c_double()
         rc2 = hh.hh_umeyama_polar(src, dst, n, R2, t2, C.byref(s2))

@@ -10,13 +10,16 @@ pipe = len(sys.argv) > 3
 bj = B.TrajectoryBatch.synthetic(nb, n, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
 oj = B.FusedPoses(bj.layout, nb, n, "cuda")
 oj.status.zero_()
-fn = (lambda: B.fuse_pipeline_batch(bj, out=oj)) if pipe else (lambda: B.ekf_fuse_batch(bj, out=oj))
+fn = (lambda: B.fuse_pipeline_batch(bj, out=oj, fit_rows=os.environ.get('FIT_ROWS', 'reference'))) if pipe else (lambda: B.ekf_fuse_batch(bj, out=oj))
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
 nch = (n + 63) // 64
-st = oj.status.cpu().numpy()[:2 * (8 + nch)].reshape(-1, 2).astype("int64")
-names = ["entry", "first fix found", "moments loop done", "reductions done", "umeyama_finalize done", "pose 0 aligned", "prelude done",
+raw = oj.status.cpu().numpy()
+st = raw[:2 * (8 + nch)].reshape(-1, 2).astype("int64")
+if raw[30] or raw[31]:
+    print(f"(stamp 15, gap check of the last round done: cycles {int(raw[30]) - int(raw[0])}, {(int(raw[31]) - int(raw[1])) / 100.0:.2f} us after entry)")
+names = ["entry", "rows of the (last) round arrived", "moments loop done", "reductions done", "umeyama_finalize done", "pose 0 aligned", "prelude done",
          "chunk 0 arrived"] + [f"chunk {k} done" for k in range(nch)]
 c0, w0 = st[0]
 prev = (c0, w0)

@@ -16,8 +16,9 @@ for variant in (0, 1):
             tot += 4000
             print(f"variant {variant} seed {seed} N {N}: {len(fb)} fallbacks of 4000", flush=True)
             for b in fb[:40]:
+                rows[f"v{variant}_s{seed}_n{N}_b{b}_ts"] = bt.ts[b].cpu().numpy()
                 rows[f"v{variant}_s{seed}_n{N}_b{b}_pos"] = bt.pos[b].cpu().numpy()
                 rows[f"v{variant}_s{seed}_n{N}_b{b}_gps"] = bt.gps[b].cpu().numpy()
                 rows[f"v{variant}_s{seed}_n{N}_b{b}_valid"] = bt.valid[b].cpu().numpy()
-np.savez_compressed(sys.argv[1], **rows)
-print("saved", len(rows) // 3, "tracks")
+np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/fallbacks.npz", **rows)
+print("saved", len(rows) // 4, "tracks")

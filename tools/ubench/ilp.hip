@@ -244,10 +244,18 @@ template <class K> void run(const char* name, K kern, int ch, int per_iter, int 
 {
     double* d; long long* c; hipMalloc(&d, (size_t)blocks * threads * 8); hipMalloc(&c, 8);
     const int iters = 2000;
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, c, iters);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, c, iters);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, c, iters);
+    hipEventRecord(e1);
     hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-    printf("%-28s chains %d: %.2f cycles per instruction (%.2f per chain step)\n", name, ch, (double)h / ((double)iters * per_iter * ch), (double)h / ((double)iters * per_iter));
+    // (the launch is ~0.1-1 ms of pure loop: the event time over the loop's clock64() count gives the rate of that counter)
+    printf("%-28s chains %d: %.2f cycles per instruction (%.2f per chain step)   [clock64 ticks at >= %.0f MHz: %lld ticks in %.1f us]\n", name, ch,
+           (double)h / ((double)iters * per_iter * ch), (double)h / ((double)iters * per_iter), (double)h / (ms * 1e3), h, ms * 1e3);
+    hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(d); hipFree(c);
 }
 int main(int argc, char** argv)

@@ -12,7 +12,7 @@ B.context().set_option("duo_kernel", int(os.environ.get("DUO", "0")))
 bj = B.TrajectoryBatch.synthetic(nb, n, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
 oj = B.FusedPoses(bj.layout, nb, n, "cuda")
 oj.status = torch.zeros(2 * nb, dtype=torch.int32, device="cuda")
-fn = (lambda: B.fuse_pipeline_batch(bj, out=oj)) if pipe else (lambda: B.ekf_fuse_batch(bj, out=oj))
+fn = (lambda: B.fuse_pipeline_batch(bj, out=oj, fit_rows=os.environ.get('FIT_ROWS', 'reference'))) if pipe else (lambda: B.ekf_fuse_batch(bj, out=oj))
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
