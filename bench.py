@@ -663,7 +663,7 @@ def worker(args):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
     pipe = args.kernel == "pipeline"
-    blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024
+    blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024 and not (args.kernel == "pipeline" and args.fit_rows == "reference")   # (its fit sees every valid row only)
     lane_route = time_major and Bn >= 32768 and not any(kv.replace(" ", "").startswith("lane_min_traj=") for kv in args.set_option)
     if lane_route:
         # lane per trajectory (gsf_ekf.hip): <LAYOUT, prefetch depth, waves per SIMD>
@@ -1135,6 +1135,7 @@ def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768, fit_r
                                                     "status_words_equal": all(g["status_words_equal"] for g in gates)}
                 except Exception as e:
                     res[lname]["gate_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                view = pos_k = gates = None                              # views of the shard: dropped with it, or the other layout has no room
             del bt, out, R, t, s, status
         except Exception as e:                                             # e.g. out of memory on a smaller card: reported, not fatal
             res[lname] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed sample line (profiles/r03_bench_default_under_rocprof.json: the default
+"""The bench.py output contract, checked on the committed sample line (profiles/r04_bench_default_under_rocprof.json: the default
 `python bench.py` run of make_profiles.sh on an MI355X) and on bench.py's own constants and helpers -- CPU tier, no GPU needed."""
 import ast
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r03_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r04_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -47,10 +47,10 @@ def test_committed_traffic_profile_matches_the_kernel_sources():
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
     assert doc["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/make_profiles.sh + tools/collect_profiles.py after changing a kernel"
     got, src = bench.profiled_traffic("c2", "ekf_wave_kernel<true, true, 1>", 64000)
-    assert src == "r03_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
+    assert src == "r04_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
     v = bench.profiled_issue("c2", "ekf_wave_kernel<true, true, 1>", 64000, 0.018)
     assert v is not None and 4.0e6 < v["valu_wave_instructions_per_launch"] < 6.0e6 and 0.3 < v["frac"] < 0.6
 

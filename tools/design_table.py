@@ -4,7 +4,7 @@ rocprofv3's average duration of that kernel at that grid in the kernel trace of 
 tools/bench_kernels.py for the auxiliary kernels), traffic = the PMC passes collected in rNN_traffic.json.  The table between the
 markers in DESIGN.md is REPLACED, so the document cannot quote a number the profiles do not hold.
 
-usage: python tools/design_table.py [r03] [--check]     (--check: exit 1 if DESIGN.md is not up to date)"""
+usage: python tools/design_table.py [r04] [--check]     (--check: exit 1 if DESIGN.md is not up to date)"""
 import csv
 import json
 import os
@@ -16,7 +16,7 @@ HBM = 8000.0
 
 # (file, kernel as rocprof names it, grid threads) -> (row label, units, algorithmic bytes per launch, unit name)
 ROWS = [
-    ("bench_default", "ekf_wave_kernel<true, true, 1>", 64000, "**C2 1 000 x 271 (bench default), fused pipeline**", 271_000, 271_000 * 145, "poses"),
+    ("bench_default", "ekf_wave_kernel<true, true, 1>", 64000, "**C2 1 000 x 271 (bench default), fused pipeline, the reference's Sim3 rows**", 271_000, 271_000 * 145, "poses"),
     ("bench_default", "ekf_wave_big_kernel<true, 1>", 6400000, "C3 100 000 x 1 000, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_wave_big_kernel<false, 1>", 6400000, "C3, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_wave_big_kernel<true, 1>", 2097152, "C5 shard chunk 32 768 x 1 000 (38 per pass), fused pipeline", 32_768_000, 32_768_000 * 145, "poses"),
@@ -24,6 +24,7 @@ ROWS = [
     ("bench_default", "fuse_pipeline_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_fuse_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "windows_fused_kernel", 1000064, "C4 1 M windows x 50 pairs (Umeyama)", 1_000_000, 1_000_000 * 2504, "windows"),
+    ("bench_default", "sim3_rows_kernel", 64000, "row choice (ref :973-998) on its own: first stage of the robust chain, 1 000 x 271", 271_000, None, "rows"),
     ("aux", "apply_sim3_slab_kernel", 25600000, "K3 apply Sim3, 1e8 poses", 100_000_000, 100_000_000 * 112, "poses"),
     ("aux", "utm_kernel<false>", 25600000, "K1 UTM forward, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "utm_kernel<true>", 25600000, "K1 UTM inverse, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
@@ -89,7 +90,7 @@ def table(tag):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r03"
+    tag = args[0] if args else "r04"
     path = os.path.join(ROOT, "DESIGN.md")
     doc = open(path).read()
     if BEGIN not in doc or END not in doc:

@@ -31,14 +31,14 @@ fi
 if want ab; then
 # 2b. the C2 launch by the other kernels, same counters (A/B for DESIGN.md section 5): K4 alone by the wave kernel, and the
 #     workgroup-per-trajectory kernel (fused pipeline and K4 alone)
-for spec in "c2ekf:--kernel ekf" "c2block:--set-option block_kernel=1" "c2blockekf:--kernel ekf --set-option block_kernel=1"; do
+for spec in "c2ekf:--kernel ekf" "c2block:--set-option block_kernel=1 --fit-rows all" "c2blockekf:--kernel ekf --set-option block_kernel=1"; do
   wl=${spec%%:*}; fl=${spec#*:}
   for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
     n=$(echo $p | cut -d" " -f1)
     timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload c2 $fl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
   done
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2block -- python3 $R/bench.py --workload c2 --set-option block_kernel=1 --no-extra --no-cpu-baseline > $OUT/bench_c2block.json 2> $OUT/bench_c2block.err || echo "trace c2block failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2block -- python3 $R/bench.py --workload c2 --set-option block_kernel=1 --fit-rows all --no-extra --no-cpu-baseline > $OUT/bench_c2block.json 2> $OUT/bench_c2block.err || echo "trace c2block failed"
 ls $OUT
 fi
 if want aux; then

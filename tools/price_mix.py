@@ -11,9 +11,12 @@ by itself; gpurun_out/r4a/ilp_w1.log), and the dynamic counts are the hardware's
   * the remaining VALU instructions (cross-lane moves, v_readlane, compares, selects, integer / mask work) are split by the STATIC census of
     the chunk loop's scan stages in the shipped object: DPP moves by control (row_shr / quad_perm inside a 16-lane row vs row_bcast /
     wave_shr across rows) are counted from the disassembly of the loop blocks that hold the scans (they execute once per chunk);
-  * time per chunk: the same subtraction on the kernel time of the two launches.
+  * time per chunk: (i) the in-kernel clock64 stamps of a clean track (tools/chunk_timing.py on the `make timing` build; pass the cycles with
+    --stamp-cycles=N), the like-for-like figure for the per-class costs, which are in clock64 cycles too; (ii) the launch-level increment:
+    kernel time at 320 poses minus kernel time at 256 poses from CLEAN (unprofiled) runs of the same two commands (--clean=DIR with
+    chunk_time_{ekf,pipeline}.jsonl) -- that one belongs to the slowest wave of the launch.
 
-usage: python tools/price_mix.py [gpurun_out/pmc_classes] [--json out.json]
+usage: python tools/price_mix.py [gpurun_out/pmc_classes] [--stamp-cycles=3724] [--clean=gpurun_out/r4t] [--json=profiles/r04_chunk_price.json]
 """
 import collections
 import csv
@@ -54,12 +57,18 @@ def read_counters(d):
 
 
 def kernel_ms(d, k, n):
+    """best kernel time of the CLEAN runs (bench.py --poses n, no profiler) listed in d/chunk_time_<k>.jsonl"""
     ms = []
-    for f in glob.glob(os.path.join(d, f"{k}_n{n}_p*.json")):
-        try:
-            ms.append(json.loads(open(f).read().strip().splitlines()[-1])["roofline"]["kernel_ms"])
-        except Exception:
-            pass
+    path = os.path.join(d, f"chunk_time_{k}.jsonl") if d else None
+    if path and os.path.exists(path):
+        for line in open(path):
+            if line.startswith("{"):
+                try:
+                    r = json.loads(line)
+                    if r["config"]["poses_per_trajectory"] == n:
+                        ms.append(r["roofline"]["kernel_ms"])
+                except Exception:
+                    pass
     return min(ms) if ms else None
 
 
@@ -103,6 +112,9 @@ def static_dpp_split():
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     d = args[0] if args else os.path.join(ROOT, "gpurun_out", "pmc_classes")
+    opt = {a.split("=", 1)[0]: a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+    clean = opt.get("--clean")
+    stamp_cycles = float(opt["--stamp-cycles"]) if "--stamp-cycles" in opt else None
     cnt = read_counters(d)
     stat = static_dpp_split()
     out = {"costs_cycles_per_instruction": COST, "clock_GHz": CLOCK_GHZ, "source": "tools/pmc_classes.sh (rocprofv3 --pmc) + tools/ubench/ilp.hip costs", "kernels": {}}
@@ -115,7 +127,7 @@ def main():
         fp = sum(per.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
         trans = per.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
         valu = per.get("SQ_INSTS_VALU", 0.0)
-        s = stat[k]
+        s = stat["ekf"]                                                    # the chunk loop's scans are the same in both kernels (the pipeline kernel's prelude has butterflies of its own)
         # v_readlane count of a chunk: carries + lane broadcasts; static count of the hot loop is not separable from cold blocks, so the
         # readlanes inside the scan blocks are taken as a lower bound and the rest stays in "valu_other"
         classes = {"fp64_fma_mul_add": fp, "fp64_trans": trans, "dpp_in_row": s["dpp_in_row"], "dpp_cross_row": s["dpp_cross_row"],
@@ -125,18 +137,18 @@ def main():
         classes["lds"] = per.get("SQ_INSTS_LDS", 0.0)
         classes["vmem"] = per.get("SQ_INSTS_VMEM", 0.0)
         cyc = {c: n * COST[c] for c, n in classes.items()}
-        t256, t320 = kernel_ms(d, k, 256), kernel_ms(d, k, 320)
+        t256, t320 = kernel_ms(clean, k, 256), kernel_ms(clean, k, 320)
         chunk_us = (t320 - t256) * 1e3 if t256 and t320 else None
         flat4 = (valu) * 4.0
         row = {"dynamic_instructions_per_chunk": {c: round(n, 1) for c, n in classes.items()}, "valu_total": round(valu, 1),
                "raw_counter_differences_per_wave": {c: round(v, 1) for c, v in per.items()},
                "class_weighted_cycles_per_chunk": round(sum(cyc.values()), 0), "cycles_by_class": {c: round(v, 0) for c, v in cyc.items()},
                "flat_4_cycle_valu_floor_cycles": round(flat4, 0),
-               "measured_us_per_chunk": chunk_us, "measured_cycles_per_chunk_at_2p4GHz": round(chunk_us * 1e3 * CLOCK_GHZ, 0) if chunk_us else None}
-        if chunk_us:
-            meas = chunk_us * 1e3 * CLOCK_GHZ
-            row["class_weighted_floor_over_measured"] = round(sum(cyc.values()) / meas, 3)
-            row["flat_floor_over_measured"] = round(flat4 / meas, 3)
+               "launch_level_us_per_added_chunk": chunk_us}
+        if stamp_cycles and k == "ekf":
+            row["clean_track_cycles_per_chunk_by_in_kernel_stamps"] = stamp_cycles
+            row["class_weighted_floor_over_measured"] = round(sum(cyc.values()) / stamp_cycles, 3)
+            row["flat_floor_over_measured"] = round(flat4 / stamp_cycles, 3)
         out["kernels"][k] = row
     txt = json.dumps(out, indent=1)
     print(txt)
