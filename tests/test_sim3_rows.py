@@ -299,3 +299,89 @@ def test_synthetic_batch_reference_rows_vs_oracle(B, orc):
             else:
                 changed = int((np.abs(R - Rref).max(axis=1) > 0).sum())
         assert changed >= nb // 40, (nb, N, changed)                                      # the mid-track outages really change the fit
+
+
+def _random_gap_tracks(nb, N, seed, max_gap, max_dur):
+    """Tracks that exercise every way the row rule can cut: outages of 1..N/2 rows (a gap shows only if the hole is longer than max_gap),
+    stamp jumps between two valid rows (a gap with no invalid row in it), stamps that run past max_dur early or never, repeated stamps,
+    NaN fixes with the mask still set, tracks with fewer valid rows than min_samples."""
+    rng = np.random.default_rng(seed)
+    rate = rng.choice([0.1, 0.5, 2.0], size=(nb, 1)) * max_gap / 5.0                       # seconds per row: 50 / 10 / 2.5 rows per max_gap
+    dt = rate * (1.0 + rng.uniform(-0.04, 0.04, size=(nb, N))); dt[:, 0] = 0.0
+    dt[rng.random((nb, N)) < 0.01] = 0.0
+    jump = rng.random((nb, N)) < (1.5 / N)
+    dt[jump] += rng.choice([0.98, 1.0, 1.02, 3.0], size=int(jump.sum())) * max_gap        # at, just under and just over the threshold
+    ts = 1.7e9 + np.cumsum(dt, axis=1)
+    valid = np.ones((nb, N), dtype=np.uint8)
+    for b in range(nb):
+        for _ in range(rng.integers(0, 4)):
+            L = int(rng.choice([1, 2, 3, 9, 11, 49, 51, 64, 130, max(1, N // 2)]))
+            s = int(rng.integers(0, max(1, N - L)))
+            valid[b, s:s + L] = 0
+        if rng.random() < 0.1: valid[b, :int(rng.integers(1, max(2, N // 3)))] = 0
+        if rng.random() < 0.1: valid[b, N - int(rng.integers(1, max(2, N // 3))):] = 0
+        if rng.random() < 0.03: valid[b, rng.permutation(N)[:max(0, N - int(rng.integers(0, 6)))]] = 0   # 0..5 valid rows left
+    head = np.cumsum(rng.normal(0, 0.02, size=(nb, N)), axis=1)
+    pos = np.cumsum(np.stack([np.cos(head), np.sin(head), 0.02 * np.ones_like(head)], -1) * 0.7, axis=1) + rng.normal(0, 0.01, size=(nb, N, 3))
+    quat = np.stack([np.zeros_like(head), np.zeros_like(head), np.sin(head / 2), np.cos(head / 2)], -1)
+    gps = pos * 1.02 + np.array([4.5e5, 5.4e6, 110.0]) + rng.normal(0, 0.3, size=(nb, N, 3))
+    gps[valid == 0] = np.nan
+    nanfix = (rng.random((nb, N)) < 0.004) & (valid == 1)
+    gps[nanfix, rng.integers(0, 3)] = np.nan
+    return ts, pos, quat, gps, valid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,par", [(5, (4, 5.0, 180.0)), (64, (4, 5.0, 3.0)), (65, (6, 2.0, 180.0)), (271, (4, 5.0, 180.0)), (271, (4, 5.0, 12.0)),
+                                   (777, (10, 1.0, 30.0)), (1000, (4, 5.0, 180.0)), (1000, (4, 0.5, 1e9))])
+def test_random_gap_structures_device_rows_equal_the_oracle_rule(B, orc, N, par):
+    """The row rule on random gap structures and CONFIG values, 2 304 tracks per case (the fused pipeline then runs the big-batch build, a
+    slice of 96 the small one): (1) gsf_sim3_fit_rows_batch_dev's mask, count and branch == the oracle's rule row for row; (2) the fused
+    pipeline's row bits, fit and poses == the oracle's pipeline under the same rule."""
+    from gps_optimize_slam_amd import ekfgpsslam as E
+    ms, gap, dur = par
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in E.CONFIG.items()}
+    cfg["sim3_ransac"]["min_samples"] = ms; cfg["time_alignment"]["max_gps_gap_threshold"] = gap; cfg["sim3_ransac"]["max_initial_duration"] = dur
+    nb = 2304
+    ts, pos, quat, gps, valid = _random_gap_tracks(nb, N, 31 * N + ms, gap, dur)
+    usable = (valid != 0) & np.isfinite(gps).all(axis=2)
+    mask, nr, st = B.sim3_fit_rows_batch(_dev(ts), _dev(gps), _dev(valid), cfg)
+    mask, nr, st = mask.cpu().numpy(), nr.cpu().numpy(), st.cpu().numpy()
+    seen = set()
+    for b in range(nb):
+        idx, br = orc.pick_sim3_rows(ts[b], usable[b], ms, gap, dur, return_branch=True)
+        if idx is None:
+            assert nr[b] == -1 and st[b] == FEW and not mask[b].any(), b
+            seen.add("few")
+            continue
+        want = np.zeros(N, np.uint8); want[idx] = 1
+        assert (mask[b] == want).all(), (b, np.nonzero(mask[b] != want)[0][:6].tolist())
+        assert nr[b] == len(idx) and st[b] == {0: 0, 1: ROWS_SEG, 2: ROWS_ALL}[br], (b, br)
+        seen.add(br)
+        if len(idx) < usable[b].sum(): seen.add("cut")
+    assert N < 64 or ("cut" in seen and {0, "few"} <= seen), seen
+    # the fused pipeline: big-batch build on the whole batch, small build on a slice -- same bits between them, oracle on a sample
+    ip = np.zeros((nb, 3)); iq = np.tile([0.0, 0.0, 0.0, 1.0], (nb, 1))
+    batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=0)
+    out, R, t, s = B.fuse_pipeline_batch(batch, config=cfg)
+    p, q, stp = out.host_traj_major()
+    small = B.TrajectoryBatch.from_host(ts[:96], pos[:96], quat[:96], gps[:96], valid[:96], ip[:96], iq[:96], layout=0)
+    B.context().set_option("duo_kernel", 0)
+    try:
+        o2, R2, _, _ = B.fuse_pipeline_batch(small, config=cfg)
+    finally:
+        B.context().set_option("duo_kernel", -1)
+    p2, q2, st2 = o2.host_traj_major()
+    np.testing.assert_array_equal(st2, stp[:96])
+    np.testing.assert_array_equal(np.nan_to_num(p2, nan=-1.0), np.nan_to_num(p[:96], nan=-1.0))
+    np.testing.assert_array_equal(np.nan_to_num(R2.cpu().numpy(), nan=-1.0), np.nan_to_num(R.cpu().numpy()[:96], nan=-1.0))
+    sel = np.unique(np.concatenate([np.arange(0, nb, 24), np.where(nr < 0)[0][:16], np.where(st != 0)[0][:32]]))
+    po, qo, sto, Ro, to, so, nro = orc.fuse_pipeline_batch(ts[sel], pos[sel], quat[sel], gps[sel], valid[sel], cfg=cfg, fit_rows="reference", return_rows=True)
+    np.testing.assert_array_equal(nro, nr[sel])
+    rowbits = (FEW | ROWS_ALL | ROWS_SEG) << 8
+    assert ((stp[sel] & rowbits) == (sto & rowbits)).all()
+    assert ((stp[sel] & 0xff) == (sto & 0xff)).all()
+    ok = np.isfinite(po).all(axis=(1, 2))
+    assert (np.isfinite(p[sel]).all(axis=(1, 2)) == ok).all()
+    # (tracks whose chosen rows are nearly collinear have an ill-conditioned fit: compared through the poses they produce)
+    assert np.abs(p[sel][ok] - po[ok]).max() < 1e-5 and np.median(np.abs(p[sel][ok] - po[ok]).max(axis=(1, 2))) < POS_TOL
