@@ -1,4 +1,4 @@
-"""CPU tier: the N>1 path (sharding + the all-gather collect) with world_size-2 gloo processes."""
+"""CPU tier: the N>1 path (sharding + the all-gather collect) with world_size-2 and world_size-8 gloo processes."""
 import os
 import sys
 
@@ -64,8 +64,10 @@ def _worker(rank, world, port, total, n, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_world2_gloo_allgather(tmp_path):
-    world, total, n = 2, 10, 5
+@pytest.mark.parametrize("world,total,n", [(2, 10, 5), (8, 32, 3)])
+def test_world2_gloo_allgather(tmp_path, world, total, n):
+    """world 2: the contract's minimum; world 8: the rank count of the driver's scaling run (one process per GPU of a node), rehearsed on
+    the host cores -- the shard ranges, the all-gather collect in both layouts, its chunked form and the max-over-ranks timing."""
     port = 29000 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, total, n, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
