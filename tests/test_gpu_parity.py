@@ -942,6 +942,39 @@ def test_capi_error_paths(B):
         _lib.check(L.gsf_set_option(h, b"no_such_option", 1))
     # B == 0 is a no-op success on every batched entry
     assert L.gsf_utm_forward_batch_dev(h, None, None, offs.data_ptr(), offs.data_ptr(), offs.data_ptr(), 0, None, None) == 0
+    # the row rule of the global Sim3 (gsf_set_sim3_rows) and the mask entry (gsf_sim3_fit_rows_batch*)
+    assert L.gsf_set_sim3_rows(h, 2, 4, 5.0, 180.0) == 1 and "mode" in _lib.last_error()
+    assert L.gsf_set_sim3_rows(h, 1, -1, 5.0, 180.0) == 1
+    assert L.gsf_set_sim3_rows(None, 1, 4, 5.0, 180.0) == 1
+    m = torch.zeros(64, dtype=torch.uint8, device="cuda"); n = torch.zeros(4, dtype=torch.int32, device="cuda")
+    assert L.gsf_sim3_fit_rows_batch_dev(h, None, None, m.data_ptr(), None, 1, 8, 4, 5.0, 180.0, m.data_ptr(), n.data_ptr(), n.data_ptr()) == 1
+    assert L.gsf_sim3_fit_rows_batch_dev(h, x.data_ptr(), None, m.data_ptr(), None, -1, 8, 4, 5.0, 180.0, m.data_ptr(), n.data_ptr(), n.data_ptr()) == 1
+    assert L.gsf_sim3_fit_rows_batch_dev(h, x.data_ptr(), None, m.data_ptr(), None, 0, 8, 4, 5.0, 180.0, m.data_ptr(), n.data_ptr(), n.data_ptr()) == 0
+    assert L.gsf_sim3_fit_rows_batch(h, None, None, None, None, 1, 8, 4, 5.0, 180.0, None, None, None) == 1
+    assert L.gsf_trim(None) == 1
+    B.context().set_sim3_rows("reference", B.CONFIG)                      # (the failed calls above changed nothing)
+
+
+def test_trim_releases_the_workspaces_and_the_next_call_regrows_them(B):
+    """gsf_trim: the grow-only arenas of a context (staging of the host-pointer entries, K2b rows, draw tape) go back to the driver; the same
+    call afterwards allocates again and returns the same bits."""
+    import torch
+    from gps_optimize_slam_amd import _lib
+    ctx = B.context()
+    bt = B.TrajectoryBatch.synthetic(64, 271, layout=0, seed=3)
+    seeds = torch.arange(64, dtype=torch.int64)
+    a = B.fuse_pipeline_robust_batch(bt, B.mt19937_seed(seeds))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx.trim()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0                                                  # nothing is held that was not held before; usually strictly more is free
+    b = B.fuse_pipeline_robust_batch(bt, B.mt19937_seed(seeds))
+    for u, v in zip(a[:4], b[:4]):
+        u = u.pos if hasattr(u, "pos") else u; v = v.pos if hasattr(v, "pos") else v
+        assert torch.equal(torch.nan_to_num(u, nan=-1.0), torch.nan_to_num(v, nan=-1.0))
+    ctx.trim(); ctx.trim()                                                 # idempotent
 
 
 def _random_outage_batch(nb, N, seed):
