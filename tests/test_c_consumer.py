@@ -1,0 +1,76 @@
+"""The drop-in boundary used from plain C (examples/fuse_batch.c): what a cgo / JNI / FFI binding of another host language sees.
+CPU tier: include/gsf.h is valid C99 and C++11, the consumer builds warning-free against libgsf.so and fails loudly without a device.
+GPU tier: its outputs equal the Python route's bit for bit (same library, same kernels, no Python or torch in the process)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gps_optimize_slam_amd")
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    from gps_optimize_slam_amd import _lib
+    if not os.path.exists(_lib.library_path()):
+        _lib.build_library()
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "fuse_batch")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "fuse_batch.c"), "-o", out, "-L" + PKG, "-lgsf", "-Wl,-rpath," + PKG])
+    return out
+
+
+def test_header_is_plain_c_and_cxx():
+    h = os.path.join(ROOT, "include", "gsf.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", h])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c++", h])
+    src = open(h).read()
+    assert "torch" not in src.replace("torch's current stream", "") and "at::" not in src and "std::" not in src      # plain pointers and sizes only
+
+
+def _write_input(path, ts, pos, quat, gps, valid):
+    with open(path, "wb") as f:
+        np.array(ts.shape, dtype=np.int64).tofile(f)
+        for a in (ts, pos, quat, gps):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+        np.ascontiguousarray(valid, dtype=np.uint8).tofile(f)
+
+
+def test_consumer_fails_loudly_without_a_device(exe, tmp_path):
+    from gps_optimize_slam_amd import _lib
+    if _lib.load().gsf_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    ts = np.zeros((1, 4)); _write_input(tmp_path / "in.bin", ts, np.zeros((1, 4, 3)), np.zeros((1, 4, 4)), np.zeros((1, 4, 3)), np.ones((1, 4), np.uint8))
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", ["reference", "all"])
+def test_c_consumer_equals_the_python_route(exe, tmp_path, rows):
+    import torch
+    from gps_optimize_slam_amd import batch as B
+    nb, N = 96, 271
+    bt = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=11)
+    h = bt.host_traj_major()
+    _write_input(tmp_path / "in.bin", h["ts"], h["pos"], h["quat"], h["gps"], h["valid"])
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + (["all"] if rows == "all" else []), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "gfx950" in r.stdout and f"fused {nb} trajectories x {N} poses" in r.stdout
+    raw = open(tmp_path / "out.bin", "rb").read()
+    P = nb * N
+    f = np.frombuffer(raw[:8 * (nb * 13 + P * 7)], dtype=np.float64)
+    st = np.frombuffer(raw[8 * (nb * 13 + P * 7):], dtype=np.int32)
+    Rc, tc, sc = f[:nb * 9].reshape(nb, 9), f[nb * 9:nb * 12].reshape(nb, 3), f[nb * 12:nb * 13]
+    pc, qc = f[nb * 13:nb * 13 + P * 3].reshape(nb, N, 3), f[nb * 13 + P * 3:].reshape(nb, N, 4)
+    B.context().set_option("duo_kernel", -1)
+    out, R, t, s = B.fuse_pipeline_batch(bt, fit_rows=rows)
+    p, q, stp = out.host_traj_major()
+    np.testing.assert_array_equal(st, stp)
+    for a, b in ((Rc, R.cpu().numpy()), (tc, t.cpu().numpy()), (sc, s.cpu().numpy()), (pc, p), (qc, q)):
+        np.testing.assert_array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
+    assert (st & 1).any() and np.isfinite(pc).all()
