@@ -104,18 +104,41 @@ __global__ __launch_bounds__(256) void gps_rows_to_utm_kernel(const double* __re
     }
 }
 
-// geodetic -> ENU about a per-trajectory origin (ref_llh[b] = lat0, lon0, h0), lane per point
+// geodetic -> ENU about a per-trajectory origin (ref_llh[b] = lat0, lon0, h0), lane per point.
+// Measured on 1e8 points in tracks of 1 000 (round 4, same box, gpurun_out/r4z): the origin's frame costs a wave as much arithmetic as a
+// trip of 64 points, and with 256 lanes per track a wave only makes four trips -- the frame formed from TWO sincos (it was six libm calls:
+// the ECEF of the origin and its four sines / cosines separately) 1.13 -> 1.01 ms; 128 lanes per block (eight trips per frame) 0.94 ms,
+// 64 lanes 1.03 (too few waves per track in flight); several points per lane and trip with the loads up front is SLOWER (2: 1.03, 4: 1.10 ms
+// at 256 lanes -- 170 registers, three waves per SIMD instead of eight): the kernel lives on occupancy, not on ILP.
+#ifndef GSF_ENU_U
+#define GSF_ENU_U 1
+#endif
+constexpr int ENU_U = GSF_ENU_U, ENU_BLOCK = 128;
 __global__ __launch_bounds__(256) void enu_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ alt,
                                                   const int64_t* __restrict__ offsets, const double* __restrict__ ref_llh,
                                                   double* __restrict__ e, double* __restrict__ n, double* __restrict__ u)
 {
     const int64_t b = blockIdx.x;
     const int64_t i0 = offsets[b], i1 = offsets[b + 1];
-    const EnuFrame f = enu_frame(ref_llh[b * 3], ref_llh[b * 3 + 1], ref_llh[b * 3 + 2]);
-    for (int64_t i = i0 + blockIdx.y * blockDim.x + threadIdx.x; i < i1; i += (int64_t)blockDim.x * gridDim.y) {
-        double ee, nn, uu;
-        geodetic_to_enu_point(f, lat[i], lon[i], alt[i], ee, nn, uu);
-        e[i] = ee; n[i] = nn; u[i] = uu;
+    const double la0 = ref_llh[b * 3], lo0 = ref_llh[b * 3 + 1], h0 = ref_llh[b * 3 + 2];
+    if (i1 <= i0) return;
+    const int64_t lanes = (int64_t)blockDim.x * gridDim.y;
+    int64_t i = i0 + (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    double la[ENU_U], lo[ENU_U], al[ENU_U];
+#pragma unroll
+    for (int k = 0; k < ENU_U; ++k) { const int64_t j = i + k * lanes, jc = j < i1 ? j : i1 - 1; la[k] = lat[jc]; lo[k] = lon[jc]; al[k] = alt[jc]; }
+    const EnuFrame f = enu_frame(la0, lo0, h0);
+    for (; i < i1; i += lanes * ENU_U) {
+        double ee[ENU_U], nn[ENU_U], uu[ENU_U];
+#pragma unroll
+        for (int k = 0; k < ENU_U; ++k) geodetic_to_enu_point(f, la[k], lo[k], al[k], ee[k], nn[k], uu[k]);
+        const int64_t inext = i + lanes * ENU_U;
+        if (inext < i1) {                                                 // the next trip's rows, requested before this trip's stores
+#pragma unroll
+            for (int k = 0; k < ENU_U; ++k) { const int64_t j = inext + k * lanes, jc = j < i1 ? j : i1 - 1; la[k] = lat[jc]; lo[k] = lon[jc]; al[k] = alt[jc]; }
+        }
+#pragma unroll
+        for (int k = 0; k < ENU_U; ++k) { const int64_t j = i + k * lanes; if (j < i1) { e[j] = ee[k]; n[j] = nn[k]; u[j] = uu[k]; } }
     }
 }
 
@@ -180,7 +203,7 @@ int gsf_geodetic_to_enu_batch_dev(gsf_ctx* ctx, const double* lat, const double*
     GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(enu_kernel, dim3((unsigned)B, blocks_per_traj(B)), dim3(256), 0, ctx->stream, lat, lon, alt, offsets, ref_llh, east, north, up);
+    hipLaunchKernelGGL(enu_kernel, dim3((unsigned)B, blocks_per_traj(B)), dim3(ENU_BLOCK), 0, ctx->stream, lat, lon, alt, offsets, ref_llh, east, north, up);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -67,6 +67,8 @@ int hh_umeyama_polar(const double* src, const double* dst, int64_t n, double* R,
 // 1 if umeyama_rotation_polar accepts H (else the SVD route is taken)
 int hh_polar_applies(const double* H) { double R[9], tr; return umeyama_rotation_polar(H, R, tr) ? 1 : 0; }
 
+void hh_sincos(const double* x, int64_t n, double* s, double* c) { for (int64_t i = 0; i < n; ++i) gsf_sincos(x[i], s[i], c[i]); }
+
 void hh_utm_forward(const double* lat, const double* lon, int64_t n, int zone, int south, double* e, double* nn)
 {
     TmConsts c = tm_consts();

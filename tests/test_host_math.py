@@ -50,6 +50,7 @@ def hh():
     L.hh_polar_applies.argtypes = [f64p]
     L.hh_utm_forward.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
     L.hh_utm_inverse.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, f64p, f64p]
+    L.hh_sincos.argtypes = [f64p, C.c_int64, f64p, f64p]
     return L
 
 
@@ -176,6 +177,38 @@ def test_umeyama_polar_route(hh, golden):
         np.testing.assert_allclose(R2, R, atol=tol, rtol=0, err_msg=f"sigma3/sigma2 = {sv[2] / sv[1]:.3g}")
         assert abs(s2.value - s.value) < 1e-12 * s.value
     assert took > 200
+
+
+def test_sincos_of_geodetic_angles(hh):
+    """gsf_sincos (one Cody-Waite step + fdlibm's kernel polynomials, the routine K1 and the ENU kernel call): against 60-digit mpmath on
+    angles at, next to and between the multiples of pi/2, and against libm on two million angles of the geodetic range; beyond |x| = 7 it
+    IS libm."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    rng = np.random.default_rng(5)
+    k = np.arange(-4, 5) * (np.pi / 2)
+    x = np.concatenate([k, np.nextafter(k, 10), np.nextafter(k, -10), (k + rng.uniform(-1e-9, 1e-9, size=(50, 9))).ravel(), np.deg2rad(np.arange(-360.0, 361.0, 7.5)),
+                        rng.uniform(-7, 7, 3000), [0.0, -0.0, 5e-324, 1e-300, 7.0, -7.0]])
+    s, c = np.empty_like(x), np.empty_like(x)
+    hh.hh_sincos(np.ascontiguousarray(x), len(x), s, c)
+    worst = 0.0
+    for xi, si, ci in zip(x, s, c):
+        es, ec = mp.sin(mp.mpf(float(xi))), mp.cos(mp.mpf(float(xi)))
+        for got, want in ((si, es), (ci, ec)):
+            ulp = np.spacing(abs(float(want))) if float(want) != 0.0 else 5e-324
+            worst = max(worst, float(abs(mp.mpf(float(got)) - want) / ulp))
+    assert worst < 1.5, worst                                            # units in the last place of the exact value (1.3 where |r| > 1/2 > |sin r|: the reduced
+                                                                         # argument is ONE double; OpenCL allows a device libm 4)
+    x = np.concatenate([np.deg2rad(rng.uniform(-90, 90, 1_000_000)), np.deg2rad(rng.uniform(-360, 360, 1_000_000))])
+    s, c = np.empty_like(x), np.empty_like(x)
+    hh.hh_sincos(x, len(x), s, c)
+    assert np.abs(s - np.sin(x)).max() < 1.7e-16 and np.abs(c - np.cos(x)).max() < 1.7e-16
+    assert np.abs(s * s + c * c - 1.0).max() < 5e-16
+    x = np.array([7.000000001, -100.0, 1e6, 1e22, np.inf, np.nan])
+    s, c = np.empty_like(x), np.empty_like(x)
+    with np.errstate(invalid="ignore"):
+        hh.hh_sincos(x, len(x), s, c)
+        np.testing.assert_array_equal(s, np.sin(x)); np.testing.assert_array_equal(c, np.cos(x))
 
 
 def test_utm_core(hh, golden):

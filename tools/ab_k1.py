@@ -1,4 +1,4 @@
-"""A/B of K1 (UTM forward, 1e8 points) for the library named by GSF_LIBRARY."""
+"""A/B of the geodesy kernels (K1 forward / inverse, WGS84 -> ENU; 1e8 points) for the library named by GSF_LIBRARY."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,4 +17,11 @@ def timed(fn, reps=10):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-print(sys.argv[1] if len(sys.argv) > 1 else "?", "K1 fwd ms", round(timed(lambda: B.utm_forward_batch(lat, lon, offs, zone, south)), 4), "checksum", float(e.sum() + nn.sum()))
+tag = sys.argv[1] if len(sys.argv) > 1 else "?"
+print(tag, "K1 fwd ms", round(timed(lambda: B.utm_forward_batch(lat, lon, offs, zone, south)), 4), "checksum", float(e.sum() + nn.sum()))
+la2, lo2 = B.utm_inverse_batch(e, nn, offs, zone, south)
+print(tag, "K1 inv ms", round(timed(lambda: B.utm_inverse_batch(e, nn, offs, zone, south)), 4), "round trip max |d| deg", float(torch.maximum((la2 - lat).abs().max(), (lo2 - lon).abs().max())))
+alt = 110.0 + 5.0 * torch.rand(nb * n, dtype=torch.float64, device=dev, generator=g)
+ref = torch.stack([lat[offs[:-1]], lon[offs[:-1]], alt[offs[:-1]]], dim=1).contiguous()
+ee, en, eu = B.geodetic_to_enu_batch(lat, lon, alt, offs, ref)
+print(tag, "ENU ms", round(timed(lambda: B.geodetic_to_enu_batch(lat, lon, alt, offs, ref)), 4), "checksum", float(ee.sum() + en.sum() + eu.sum()))

@@ -29,7 +29,7 @@ ROWS = [
     ("aux", "utm_kernel<false>", 25600000, "K1 UTM forward, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "utm_kernel<true>", 25600000, "K1 UTM inverse, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "gps_rows_to_utm_kernel", 25600000, "geodesy slice (mask + zone + forward + alt), 1e8 rows", 100_000_000, 100_000_000 * 48, "rows"),
-    ("aux", "enu_kernel", 25600000, "WGS84 -> local ENU, 1e8 points", 100_000_000, 100_000_000 * 48, "points"),
+    ("aux", "enu_kernel", 12800000, "WGS84 -> local ENU, 1e8 points", 100_000_000, 100_000_000 * 48, "points"),
     ("aux", "ransac_batch_kernel", 256000, "K2b 1 000 x (271 points, 1 000 fed trials)", 1000, None, "trajectories"),
     ("aux", "mt_choice_kernel", 64000, "device draws: 1 000 streams x 1 000 trials of permutation(271)[:4]", 1_000_000, None, "trials"),
     ("bench_default", "mt_tape_kernel", 512, "device draws, ONE stream x 1 000 trials (C1 drop-in), chip-wide route: the tape", 1000, None, "trials"),
