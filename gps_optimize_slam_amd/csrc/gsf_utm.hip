@@ -40,8 +40,12 @@ __global__ __launch_bounds__(256) void utm_zone_kernel(const double* __restrict_
     }
 }
 
+#ifndef GSF_UTM_OCC
+#define GSF_UTM_OCC 3
+#endif
+// (three waves per SIMD: 168 registers.  Left alone the compiler takes 170 for the geodesy slice -- allocated as 176, i.e. two waves)
 template <bool INVERSE>
-__global__ __launch_bounds__(256) void utm_kernel(const double* __restrict__ a, const double* __restrict__ bb,
+__global__ __launch_bounds__(256, GSF_UTM_OCC) void utm_kernel(const double* __restrict__ a, const double* __restrict__ bb,
                                                   const int64_t* __restrict__ offsets, const int32_t* __restrict__ zone,
                                                   const int32_t* __restrict__ south, double* __restrict__ o1, double* __restrict__ o2)
 {
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void utm_kernel(const double* __restrict__ a, 
 // The geodesy slice of load_gps_data (ref :258-271) for B ragged GNSS logs in ONE launch, block per log: rows (lat, lon, alt) ->
 // validity mask (:259-264; rows the reference DROPS come back as NaN rows -- a fixed-shape device array cannot shrink), zone and
 // hemisphere from the means over the valid rows (:131-133), UTM forward, rows [E, N, alt] (:271).
-__global__ __launch_bounds__(256) void gps_rows_to_utm_kernel(const double* __restrict__ llh, const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(256, GSF_UTM_OCC) void gps_rows_to_utm_kernel(const double* __restrict__ llh, const int64_t* __restrict__ offsets,
                                                               double* __restrict__ enu, int32_t* __restrict__ zone, int32_t* __restrict__ south)
 {
     __shared__ double sh[3][4];

@@ -25,3 +25,11 @@ alt = 110.0 + 5.0 * torch.rand(nb * n, dtype=torch.float64, device=dev, generato
 ref = torch.stack([lat[offs[:-1]], lon[offs[:-1]], alt[offs[:-1]]], dim=1).contiguous()
 ee, en, eu = B.geodetic_to_enu_batch(lat, lon, alt, offs, ref)
 print(tag, "ENU ms", round(timed(lambda: B.geodetic_to_enu_batch(lat, lon, alt, offs, ref)), 4), "checksum", float(ee.sum() + en.sum() + eu.sum()))
+
+import ctypes as C
+from gps_optimize_slam_amd import _lib
+llh = torch.stack([lat, lon, alt], dim=1).contiguous()
+utm = torch.empty_like(llh); zz = torch.empty(nb, dtype=torch.int32, device=dev); ss = torch.empty(nb, dtype=torch.int32, device=dev)
+L, h = _lib.load(), B.context().handle
+run = lambda: _lib.check(L.gsf_gps_rows_to_utm_batch_dev(h, llh.data_ptr(), offs.data_ptr(), nb, utm.data_ptr(), zz.data_ptr(), ss.data_ptr()))
+print(tag, "geodesy slice ms", round(timed(run), 4), "checksum", float(utm.sum()))
