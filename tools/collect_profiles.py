@@ -33,7 +33,14 @@ if os.path.exists(raw + "/aux_kernels.json"):
     open(f"{out}/{tag}_aux_kernels.json", "w").write(txt[txt.index("{"):])
 for wl in ("c2", "c3", "c3ekf", "c2ekf", "c2block", "c2blockekf", "c5chunk", "c3lane", "c3laneekf", "c2all", "c3all", "aux"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
+    # gpurun MERGES a call's outputs into gpurun_out/: a pass that was run again leaves the earlier run's files (another pid) beside the
+    # new ones -- only the newest file of each pass directory is read
+    newest = {}
     for f in glob.glob(f"{raw}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
+        d = f[len(raw) + 1:].split(os.sep)[0]
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in sorted(newest.values()):
         for row in csv.DictReader(open(f)):
             m = pat.search(row["Kernel_Name"])
             if m:

@@ -16,15 +16,14 @@ if [ "$SECTIONS" = "all" ]; then rm -rf $OUT; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 if want trace; then
-rm -rf $OUT/trace_bench_default
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench_default -- python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "trace failed"
+rm -rf $OUT/trace_bench_default; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench_default -- python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "trace failed"
 fi
 if [ "$SECTIONS" = "trace" ]; then ls $OUT/trace_bench_default; exit 0; fi
 if want main; then
 for wl in c2 c3; do
   for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
     n=$(echo $p | cut -d" " -f1)
-    timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload $wl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
+    rm -rf $OUT/pmc_${wl}_$n; timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload $wl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
   done
 done
 fi
@@ -35,25 +34,25 @@ for spec in "c2ekf:--kernel ekf" "c2block:--set-option block_kernel=1 --fit-rows
   wl=${spec%%:*}; fl=${spec#*:}
   for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
     n=$(echo $p | cut -d" " -f1)
-    timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload c2 $fl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
+    rm -rf $OUT/pmc_${wl}_$n; timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py --workload c2 $fl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
   done
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2block -- python3 $R/bench.py --workload c2 --set-option block_kernel=1 --fit-rows all --no-extra --no-cpu-baseline > $OUT/bench_c2block.json 2> $OUT/bench_c2block.err || echo "trace c2block failed"
+rm -rf $OUT/trace_c2block; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2block -- python3 $R/bench.py --workload c2 --set-option block_kernel=1 --fit-rows all --no-extra --no-cpu-baseline > $OUT/bench_c2block.json 2> $OUT/bench_c2block.err || echo "trace c2block failed"
 ls $OUT
 fi
 if want aux; then
 # 3. the auxiliary kernels (tools/bench_kernels.py): kernel trace + PMC passes
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_aux -- python3 $R/tools/bench_kernels.py > $OUT/aux_kernels.json 2> $OUT/aux_kernels.err || echo "aux trace failed"
+rm -rf $OUT/trace_aux; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_aux -- python3 $R/tools/bench_kernels.py > $OUT/aux_kernels.json 2> $OUT/aux_kernels.err || echo "aux trace failed"
 for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
   n=$(echo $p | cut -d" " -f1)
-  timeout -k 10 600 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_aux_$n -- python3 $R/tools/bench_kernels.py > $OUT/pmc_aux_$n.json 2> $OUT/pmc_aux_$n.err || echo "pmc aux $n failed"
+  rm -rf $OUT/pmc_aux_$n; timeout -k 10 600 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_aux_$n -- python3 $R/tools/bench_kernels.py > $OUT/pmc_aux_$n.json 2> $OUT/pmc_aux_$n.err || echo "pmc aux $n failed"
 done
 fi
 if want c3ekf; then
 # 4. K4-only PMC at C3 (the committed C3 PMC of round 1 was of the pipeline kernel only)
 for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
   n=$(echo $p | cut -d" " -f1)
-  timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_c3ekf_$n -- python3 $R/bench.py --workload c3 --kernel ekf --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_c3ekf_$n.json 2> $OUT/pmc_c3ekf_$n.err || echo "pmc c3ekf $n failed"
+  rm -rf $OUT/pmc_c3ekf_$n; timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_c3ekf_$n -- python3 $R/bench.py --workload c3 --kernel ekf --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_c3ekf_$n.json 2> $OUT/pmc_c3ekf_$n.err || echo "pmc c3ekf $n failed"
 done
 ls $OUT
 fi
@@ -65,7 +64,7 @@ for spec in "c5chunk:--workload c3 --traj-per-gpu 32768" "c3lane:--workload c3 -
   wl=${spec%%:*}; fl=${spec#*:}
   for p in "${PMC4[@]}"; do
     n=$(echo $p | cut -d" " -f1)
-    timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py $fl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
+    rm -rf $OUT/pmc_${wl}_$n; timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pmc_${wl}_$n -- python3 $R/bench.py $fl --no-extra --no-cpu-baseline --no-other-rows --steps 3 --warmup 1 > $OUT/pmc_${wl}_$n.json 2> $OUT/pmc_${wl}_$n.err || echo "pmc $wl $n failed"
   done
 done
 ls $OUT
