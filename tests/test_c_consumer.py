@@ -67,9 +67,14 @@ def test_c_consumer_equals_the_python_route(exe, tmp_path, rows):
     st = np.frombuffer(raw[8 * (nb * 13 + P * 7):], dtype=np.int32)
     Rc, tc, sc = f[:nb * 9].reshape(nb, 9), f[nb * 9:nb * 12].reshape(nb, 3), f[nb * 12:nb * 13]
     pc, qc = f[nb * 13:nb * 13 + P * 3].reshape(nb, N, 3), f[nb * 13 + P * 3:].reshape(nb, N, 4)
-    B.context().set_option("duo_kernel", -1)
-    out, R, t, s = B.fuse_pipeline_batch(bt, fit_rows=rows)
-    p, q, stp = out.host_traj_major()
+    ctx = B.context()
+    was = ctx.options.get("block_kernel", -1)              # (a test tier may route this process through the opt-in block kernel by environment;
+    ctx.set_option("duo_kernel", -1); ctx.set_option("block_kernel", -1)   #  the C process has the library's defaults)
+    try:
+        out, R, t, s = B.fuse_pipeline_batch(bt, fit_rows=rows)
+        p, q, stp = out.host_traj_major()
+    finally:
+        ctx.set_option("block_kernel", was)
     np.testing.assert_array_equal(st, stp)
     for a, b in ((Rc, R.cpu().numpy()), (tc, t.cpu().numpy()), (sc, s.cpu().numpy()), (pc, p), (qc, q)):
         np.testing.assert_array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
