@@ -21,6 +21,7 @@ C5-shaped leg ("c5") reports compute-only vs compute+gather rates and per-link G
 Prints ONE JSON line on rank 0 (contract in the round brief): metric/value/unit + roofline + cpu_baseline.
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
@@ -117,18 +118,18 @@ def usable_cores():
 
 
 def reference_python_timing():
-    """tools/reference_timing.json: the REFERENCE ITSELF (EKFGPSSLAM.py, stubbed import) timed next to the oracle in the build container
-    by tools/time_reference.py -- the reference's files never travel to the GPU box, so this is a committed measurement, quoted."""
+    """profiles/rNN_reference_timing.json: the REFERENCE ITSELF (EKFGPSSLAM.py, stubbed import) timed next to the oracle in the build container
+    by tests/campaigns/time_reference.py -- the reference's files never travel to the GPU box, so this is a committed measurement, quoted."""
     try:
-        d = json.load(open(os.path.join(ROOT, "tools", "reference_timing.json")))
+        d = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_timing.json")))[-1]))
         h = d["headline"]
         return {"reference_python_poses_per_s": h["reference_python_poses_per_s"], "oracle_poses_per_s_same_inputs_same_box": h["oracle_poses_per_s_same_inputs"],
                 "oracle_over_reference": h["oracle_over_reference"], "what": h["what"],
-                "where": f"{d['where']}, {d['cpu']}, {d['cores_used']} core, {d['date']} (tools/time_reference.py; the reference is single-threaded Python)",
+                "where": f"{d['where']}, {d['cpu']}, {d['cores_used']} core, {d['date']} (tests/campaigns/time_reference.py; the reference is single-threaded Python)",
                 "steps_2_to_5_reference_poses_per_s": d["cases"]["synthetic_271_with_outage"]["steps_2_to_5"]["reference_poses_per_s"],
                 "robust_fit_reference_ms": d["cases"]["synthetic_271_with_outage"]["compute_sim3_transform_robust"]["reference_ms"]}
     except Exception as e:
-        return {"error": f"tools/reference_timing.json unreadable: {e}"[:200]}
+        return {"error": f"profiles/rNN_reference_timing.json unreadable: {e}"[:200]}
 
 
 def cpu_baseline(B_mod, N, target_seconds=8.0, fit_rows="reference"):

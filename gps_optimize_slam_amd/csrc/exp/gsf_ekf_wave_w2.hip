@@ -1,6 +1,6 @@
 // exp/gsf_ekf_wave_w2.hip -- EXPERIMENT, not part of libgsf.so (`make wave2` builds ../libgsf_wave2.so with this unit in place of
 // gsf_ekf_wave.o): the small-batch wave-per-trajectory route with TWO poses per lane (exp/gsf_wave2.hpp).  Parity-green against the
-// oracle on every track length tried (tools/experiments/wave2_check.py) and SLOWER than the shipped kernel: DESIGN.md section 5,
+// oracle on every track length tried (tests/campaigns/wave2_check.py) and SLOWER than the shipped kernel: DESIGN.md section 5,
 // "two poses per lane".  The shipped translation unit is included unchanged, its launcher under another name.
 #include "../gsf_wave_common.hpp"
 #define launch_ekf_wave launch_ekf_wave_shipped

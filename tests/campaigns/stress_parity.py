@@ -1,7 +1,7 @@
 """One-off large randomised parity sweep (GPU box): every default K4 build against the oracle on tens of thousands of tracks with
 random outage / sharp-turn / NaN-fix patterns (the generator of tests/test_gpu_parity.py).  usage: stress_parity.py [NB] [N] [SEED]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

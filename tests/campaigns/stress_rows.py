@@ -3,7 +3,7 @@ next to the threshold, NaN fixes, random CONFIG values (min_samples, max_gps_gap
 gsf_sim3_fit_rows_batch_dev's mask / count / branch against the oracle's rule row for row, and the fused pipeline's row bits and poses against the
 oracle's pipeline on a sample of every batch.  usage: stress_rows.py [ROUNDS] [SEED]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -8,10 +8,10 @@ absent offline); its own functions run on one core (it is single-threaded Python
   * steps 2-5 of main_process_gui (:971-1010)          -> poses per second end to end
 on (i) the bundled KITTI-04 track against its GNSS file (config C1), (ii) a 271-pose and (iii) a 1 000-pose synthetic track with a
 mid-track outage (the shape of the bench batches).  The oracle (oracle/gsf_oracle.c, the bench's cpu_baseline "port") runs on the
-same inputs, so the ratio port / reference is on record.  Writes tools/reference_timing.json, which bench.py quotes beside
+same inputs, so the ratio port / reference is on record.  Writes profiles/r04_reference_timing.json, which bench.py quotes beside
 cpu_baseline.value and BASELINE.md section 2 tabulates.
 
-    python tools/time_reference.py
+    python tests/campaigns/time_reference.py
 """
 import contextlib
 import datetime
@@ -24,7 +24,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 REF = "/root/reference"
@@ -42,7 +42,7 @@ def best_of(fn, repeats):
 
 def main():
     if not os.path.isdir(REF):
-        sys.exit("tools/time_reference.py runs in the build container only: /root/reference is not here")
+        sys.exit("tests/campaigns/time_reference.py runs in the build container only: /root/reference is not here")
     with contextlib.redirect_stdout(io.StringIO()):
         import gen_golden as G                                            # imports the reference (stubbed pyproj / tkinter), nothing else
     ref = G.ref
@@ -122,7 +122,7 @@ def main():
                        "oracle_poses_per_s_same_inputs": c271["apply_ekf_correction"]["oracle_poses_per_s"],
                        "oracle_over_reference": c271["apply_ekf_correction"]["oracle_over_reference"],
                        "what": "apply_ekf_correction (EKFGPSSLAM.py:831-935) on a 271-pose synthetic track with one outage, best of 3, one core"}
-    path = os.path.join(ROOT, "tools", "reference_timing.json")
+    path = os.path.join(ROOT, "profiles", "r04_reference_timing.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)

@@ -1,6 +1,6 @@
 """Experiment driver (GPU box): the two-poses-per-lane chunk loop (csrc/exp/gsf_wave2.hpp, `make wave2`, GSF_LIBRARY=.../libgsf_wave2.so)
 against the oracle on random outage / sharp-turn / NaN-fix tracks of many lengths, K4 and fused pipeline, then its kernel time next to the
-shipped kernel's.  usage: GSF_LIBRARY=... python tools/experiments/wave2_check.py [check|time|both] [NB]"""
+shipped kernel's.  usage: GSF_LIBRARY=... python tests/campaigns/wave2_check.py [check|time|both] [NB]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,7 +2,7 @@
 T=gpurun_out/$1; mkdir -p $T
 export W2=$PWD/gps_optimize_slam_amd/libgsf_wave2.so
 if [ "$2" = check ]; then
-GSF_LIBRARY=$W2 timeout -k 10 500 python tools/experiments/wave2_check.py check 600 > $T/check.log 2>&1
+GSF_LIBRARY=$W2 timeout -k 10 500 python tests/campaigns/wave2_check.py check 600 > $T/check.log 2>&1
 echo "check rc=$?" >> $T/check.log
 fi
 GSF_LIBRARY=$PWD/gps_optimize_slam_amd/libgsf_wave2_timing.so python tools/chunk_timing.py 1000 1000 > $T/t.log 2>&1
