@@ -65,3 +65,10 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "gsf_oracle" not in txt, f
+    # ... and nothing outside tests/ does either, except the two places the rules name: smoke() and bench.py's cpu_baseline leg / gates
+    for top in ("tools", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".c", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert "import oracle" not in txt and "from oracle" not in txt and "libgsf_oracle" not in txt, os.path.join(top, f)
