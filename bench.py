@@ -934,6 +934,17 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         o = B.FusedPoses(bt.layout, 1000, 271, dev)
         extra["c2_time_major_pipeline_ms"] = timed(lambda: B.fuse_pipeline_batch(bt, out=o), 50)
         del bt, o
+        # KITTI-04-length tracks in batches of other sizes: the headline batch (1 000 tracks = one wave per SIMD) is the latency-bound end of
+        # the curve, the chip's throughput on 271-pose tracks is what the large batches show (same kernels, same bits per track)
+        sweep = {}
+        for nb_ in (256, 1000, 2048, 4096, 16384, 100_000):
+            bt = B.TrajectoryBatch.synthetic(nb_, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
+            o = B.FusedPoses(bt.layout, nb_, 271, dev)
+            ms_ = timed(lambda: B.fuse_pipeline_batch(bt, out=o, fit_rows=args.fit_rows), 50 if nb_ <= 16384 else 10)
+            sweep[str(nb_)] = {"kernel_ms_eager_launches": ms_, "poses_per_s": nb_ * 271 / ms_ * 1e3, "hbm_frac": nb_ * 271 * ALG_BYTES_PER_POSE / ms_ / 1e6 / HBM_PEAK_GBS}
+            del bt, o
+        extra["batch_size_sweep_271_pose_tracks"] = sweep
+        torch.cuda.empty_cache()
         # the path from the geodetic GNSS log (K1 -> time alignment -> fit -> EKF, one device chain) and the robust chain (device-side
         # legacy-MT19937 draws -> RANSAC -> inlier refit -> Sim3 of pose 0 -> EKF), both at the C2 shape
         gb = B.GeodeticBatch.synthetic(1000, 271, seed=SEED)
