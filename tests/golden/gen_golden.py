@@ -752,6 +752,46 @@ def gen_sim3_rows_cases():
     save("sim3_rows_cases.npz", **out)
 
 
+# --------------------------------------------------------------------------
+def gen_random_ekf_tracks():
+    """64 random 120-pose tracks through the REFERENCE's apply_ekf_correction (stacked arrays, one file): several outages per track (1 pose
+    to a third of the track, at the start, at the end), fixes that are NaN with the mask set, yaw bursts inside outages (sharp-turn
+    recoveries), repeated stamps -- the kind of input tests/test_gpu_parity.py's stress generator makes, but with the reference's own outputs,
+    so that the oracle AND the kernels are compared with the reference itself on inputs nobody picked by hand."""
+    rng = np.random.default_rng(20251004)
+    nb, n = 64, 120
+    T, P, Q, A, V, SP, SQ, OP, OQ = [], [], [], [], [], [], [], [], []
+    for b in range(nb):
+        burst = None
+        valid = np.ones(n, bool)
+        for _ in range(int(rng.integers(0, 4))):
+            L = int(rng.choice([1, 2, 3, 8, 25, 40]))
+            s0 = int(rng.integers(0, n - L))
+            valid[s0:s0 + L] = False
+            if L >= 8 and burst is None and rng.random() < 0.6:
+                a = s0 + 1 + int(rng.integers(0, L - 4))
+                burst = (a, a + 3, float(rng.choice([-1, 1]) * rng.uniform(60.0, 200.0)))
+        if rng.random() < 0.15: valid[:int(rng.integers(1, 30))] = False
+        if rng.random() < 0.15: valid[n - int(rng.integers(1, 30)):] = False
+        ts, pos, quat, gps, _, _ = synth_traj(rng, n, yaw_rate_deg=float(rng.uniform(-4, 4)), burst=burst)
+        if rng.random() < 0.3:
+            k = int(rng.integers(2, n - 2)); ts[k] = ts[k - 1]                     # repeated stamp (Q9)
+        aligned = gps.copy(); aligned[~valid] = np.nan
+        nanfix = (rng.random(n) < 0.02) & valid
+        aligned[nanfix, int(rng.integers(0, 3))] = np.nan                           # NaN fix, mask still set (Q10)
+        vi = np.where(valid & ~np.isnan(aligned).any(axis=1))[0]
+        with quiet():
+            R, t, s = (None, None, None) if len(vi) < 3 else ref.compute_sim3_transform(pos[vi], aligned[vi])
+            if R is None:
+                R, t, s = np.eye(3), np.zeros(3), 1.0
+            sp, sq = ref.transform_trajectory(pos, quat, R, t, s)
+        p, q = run_ekf(ts, pos, quat, aligned, valid, sp, sq, ref.CONFIG)
+        for lst, v in zip((T, P, Q, A, V, SP, SQ, OP, OQ), (ts, pos, quat, aligned, valid, sp[0], sq[0], p, q)):
+            lst.append(np.asarray(v))
+    save("ekf_random_tracks.npz", ts=np.stack(T), pos=np.stack(P), quat=np.stack(Q), aligned=np.stack(A), valid=np.stack(V), sp0=np.stack(SP), sq0=np.stack(SQ),
+         out_pos=np.stack(OP), out_quat=np.stack(OQ))
+
+
 if __name__ == "__main__":
     if "--only-step6" in sys.argv:
         with quiet():
@@ -760,6 +800,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-sim3-rows" in sys.argv:
         gen_sim3_rows_cases()
+        sys.exit(0)
+    if "--only-random-ekf" in sys.argv:
+        gen_random_ekf_tracks()
         sys.exit(0)
     if "--only-filter" in sys.argv:                  # later additions regenerate alone: the other files stay byte-identical
         gen_filter_cases()
@@ -774,3 +817,4 @@ if __name__ == "__main__":
     gen_filter_cases()
     gen_step6_with_ground_truth(slam)
     gen_sim3_rows_cases()
+    gen_random_ekf_tracks()

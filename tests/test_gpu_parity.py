@@ -1821,3 +1821,26 @@ def test_repeated_launches_return_the_same_bits(B):
         if first is None: first = got
         assert same(first, got), rep
         noise.mul_(1.0000001)
+
+
+@pytest.mark.gpu
+def test_random_reference_tracks_on_every_route(B, golden):
+    """K4 on 64 random outage / sharp-turn / NaN-fix tracks against the REFERENCE's own outputs (ekf_random_tracks.npz, generated by
+    apply_ekf_correction itself) -- every route: wave per trajectory (small build; big-batch build on 40 stacked copies), time-major through
+    the transposes, lane per trajectory, workgroup per trajectory."""
+    g = golden("ekf_random_tracks.npz")
+    args = [g[k] for k in ("ts", "pos", "quat")] + [g["aligned"], g["valid"].astype(np.uint8), g["sp0"], g["sq0"]]
+    for name, layout, opt, copies in (("wave", 0, None, 1), ("big-batch build", 0, None, 40), ("time-major via the wave kernel", 1, None, 1),
+                                      ("lane", 1, ("lane_min_traj", 0), 1), ("block", 0, ("block_kernel", 1), 1)):
+        a = [np.concatenate([x] * copies) for x in args]
+        batch = B.TrajectoryBatch.from_host(*a, layout=layout)
+        if opt: B.context().set_option(*opt)
+        try:
+            p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
+        finally:
+            if opt: B.context().set_option(opt[0], 32768 if opt[0] == "lane_min_traj" else -1)
+        nb = g["ts"].shape[0]
+        for c in range(0, copies, max(1, copies - 1)):                       # first and last copy
+            np.testing.assert_allclose(p[c * nb:(c + 1) * nb], g["out_pos"], atol=POS_TOL, rtol=0, err_msg=name)
+            np.testing.assert_allclose(q[c * nb:(c + 1) * nb], g["out_quat"], atol=Q_TOL, rtol=0, err_msg=name)
+        assert (st[:nb] & 1).any() and (st[:nb] & 2).any() and (st[:nb] & 4).any() and (st[:nb] & 8).any(), name

@@ -191,6 +191,23 @@ def test_ekf_cases(golden):
             assert st & 15 == expect_status[str(name)], (name, st)
 
 
+def test_random_tracks_oracle_vs_the_reference(golden):
+    """64 random outage / sharp-turn / NaN-fix tracks whose expected outputs are the REFERENCE's own apply_ekf_correction
+    (tests/golden/gen_golden.py: gen_random_ekf_tracks): inputs nobody picked by hand."""
+    g = golden("ekf_random_tracks.npz")
+    seen = 0
+    for b in range(g["ts"].shape[0]):
+        p, q, st = orc.apply_ekf_correction_aligned(g["ts"][b], g["pos"][b], g["quat"][b], g["aligned"][b], g["valid"][b], g["sp0"][b], g["sq0"][b],
+                                                    merged_cfg({}), return_status=True)
+        np.testing.assert_allclose(p, g["out_pos"][b], atol=POS_TOL, rtol=0, err_msg=str(b))
+        np.testing.assert_allclose(q, g["out_quat"][b], atol=Q_TOL, rtol=0, err_msg=str(b))
+        seen |= int(st)
+    assert seen & 15 == 15                                   # outages, RTS back-passes, sharp-turn recoveries and tracks that end in an outage all occur
+    p, q, st = orc.fuse_batch(g["ts"], g["pos"], g["quat"], g["aligned"], g["valid"].astype(np.uint8), g["sp0"], g["sq0"])
+    np.testing.assert_allclose(p, g["out_pos"], atol=POS_TOL, rtol=0)                    # the batched entry the GPU tests compare with
+    np.testing.assert_allclose(q, g["out_quat"], atol=Q_TOL, rtol=0)
+
+
 # ---------------------------------------------------------------- helpers
 def test_relative_pose_and_nlerp(golden):
     g = golden("helper_cases.npz")
