@@ -679,15 +679,8 @@ class HeadlessGui:
         return rec
 
 
-def gen_sim3_rows_cases():
-    """Which time-synchronised rows feed the global Sim3 (ref :973-998) -- decided by the reference's own main_process_gui, run
-    headless (HeadlessGui) on crafted SLAM / GNSS pairs; plus what steps 3-5 make of them (seeded draws).  The rows are recovered
-    from the (src, dst) arrays main_process_gui hands to compute_sim3_transform_robust (SLAM positions are unique)."""
-    rng = np.random.default_rng(973)
-    out, names = {}, []
-    sec = ("time_alignment", "sim3_ransac")
-    base = {k: dict(ref.CONFIG[k]) for k in sec}
-
+def _rows_case_adder(out, names, base, sec):
+    """add(name, ...): one headless run of main_process_gui on a crafted SLAM / GNSS pair, its rows, branch, fit and fused poses into `out`"""
     def add(name, ts, pos, quat, gps_rows, seed, max_dur=None, gap=None, min_samples=None, gps_t=None, gps_p=None):
         for k in sec:
             ref.CONFIG[k].clear(); ref.CONFIG[k].update(base[k])
@@ -720,6 +713,20 @@ def gen_sim3_rows_cases():
         names.append(name)
         print(f"   {name}: valid {int(np.sum(o['valid']))}/{len(ts)} -> {len(idx)} rows, branch {branch}, failed {failed}"
               + ("" if failed else f", rows {idx[0]}..{idx[-1]}") + (f" [{o['error']}]" if failed else ""))
+
+    return add
+
+
+def gen_sim3_rows_cases():
+    """Which time-synchronised rows feed the global Sim3 (ref :973-998) -- decided by the reference's own main_process_gui, run
+    headless (HeadlessGui) on crafted SLAM / GNSS pairs; plus what steps 3-5 make of them (seeded draws).  The rows are recovered
+    from the (src, dst) arrays main_process_gui hands to compute_sim3_transform_robust (SLAM positions are unique)."""
+    rng = np.random.default_rng(973)
+    out, names = {}, []
+    sec = ("time_alignment", "sim3_ransac")
+    base = {k: dict(ref.CONFIG[k]) for k in sec}
+
+    add = _rows_case_adder(out, names, base, sec)
 
     n = 300
     ts, pos, quat, gps, _, _ = synth_traj(rng, n)
@@ -792,6 +799,39 @@ def gen_random_ekf_tracks():
          out_pos=np.stack(OP), out_quat=np.stack(OQ))
 
 
+def gen_sim3_rows_random():
+    """24 RANDOM SLAM / GNSS pairs through the reference's own main_process_gui (headless): random outages (some longer than the gap
+    threshold, some not), SLAM stamp jumps at / next to the threshold, random duration limits and min_samples -- rows, branch, robust fit
+    (seeded draws) and fused poses as the reference produces them.  Same keys as sim3_rows_cases.npz."""
+    rng = np.random.default_rng(97398)
+    out, names = {}, []
+    sec = ("time_alignment", "sim3_ransac")
+    base = {k: dict(ref.CONFIG[k]) for k in sec}
+    add = _rows_case_adder(out, names, base, sec)
+    for c in range(24):
+        n = int(rng.integers(100, 161))
+        ts, pos, quat, gps, _, _ = synth_traj(rng, n, yaw_rate_deg=float(rng.uniform(-3, 3)))
+        rows = np.ones(n, bool)
+        for _ in range(int(rng.integers(0, 4))):
+            L = int(rng.choice([1, 3, 20, 48, 49, 50, 60, 70]))
+            a = int(rng.integers(0, max(1, n - L)))
+            rows[a:a + L] = False
+        if rng.random() < 0.2: rows[:int(rng.integers(1, 40))] = False
+        if rng.random() < 0.2: rows[n - int(rng.integers(1, 40)):] = False
+        if rows.sum() < 8: rows[:: max(1, n // 10)] = True
+        tsj = ts.copy()
+        if rng.random() < 0.3:
+            k = int(rng.integers(5, n - 5)); tsj[k:] += float(rng.choice([4.9, 5.05, 7.0]))          # a gap made by the SLAM stamps alone
+        kw = {}
+        if rng.random() < 0.4: kw["max_dur"] = float(rng.choice([0.25, 3.0, 6.0]))
+        if rng.random() < 0.25: kw["min_samples"] = 6
+        add(f"rnd{c:02d}", tsj, pos, quat, np.where(rows)[0], 100 + c, gps_t=tsj, gps_p=gps, **kw)
+    for k in sec:
+        ref.CONFIG[k].clear(); ref.CONFIG[k].update(base[k])
+    out["names"] = np.array(names)
+    save("sim3_rows_random.npz", **out)
+
+
 if __name__ == "__main__":
     if "--only-step6" in sys.argv:
         with quiet():
@@ -803,6 +843,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-random-ekf" in sys.argv:
         gen_random_ekf_tracks()
+        sys.exit(0)
+    if "--only-sim3-rows-random" in sys.argv:
+        gen_sim3_rows_random()
         sys.exit(0)
     if "--only-filter" in sys.argv:                  # later additions regenerate alone: the other files stay byte-identical
         gen_filter_cases()
@@ -818,3 +861,4 @@ if __name__ == "__main__":
     gen_step6_with_ground_truth(slam)
     gen_sim3_rows_cases()
     gen_random_ekf_tracks()
+    gen_sim3_rows_random()

@@ -19,9 +19,21 @@ Q_TOL = 1e-9
 FEW, ROWS_ALL, ROWS_SEG = 32, 64, 128
 
 
+class _Both:
+    """the crafted cases (sim3_rows_cases.npz) and the random ones (sim3_rows_random.npz): same keys, distinct case names"""
+    def __init__(self, *files):
+        self.files = files
+
+    def __getitem__(self, k):
+        for f in self.files:
+            if k in f.files:
+                return f[k]
+        raise KeyError(k)
+
+
 def cases(golden):
-    g = golden("sim3_rows_cases.npz")
-    return g, [str(n) for n in g["names"]]
+    a, b = golden("sim3_rows_cases.npz"), golden("sim3_rows_random.npz")
+    return _Both(a, b), [str(n) for n in a["names"]] + [str(n) for n in b["names"]]
 
 
 def case_cfg(base, par):
