@@ -287,6 +287,11 @@ __device__ __forceinline__ void chunk_arrived(const ChunkWide& c)
 {
     asm volatile("" :: "v"(c.t), "v"(c.P[0]), "v"(c.P[1]), "v"(c.Q[0]), "v"(c.Q[1]), "v"(c.Z[0]), "v"(c.Z[1]), "v"(c.v) : "memory");
 }
+// One staging area per wave for BOTH transpositions of the big-batch build -- the chunk's input pieces at the top of an iteration (64 x 10
+// doubles), its output rows at the bottom (64 x 7): each use ends on its own wait, a wave's LDS operations execute in order, and with one
+// 5 KB buffer instead of 5 + 3.5 KB a wave's LDS (with the 6 KB outage ring) drops from 14.5 to 11 KB -- twelve waves per CU (three per SIMD,
+// what the registers allow) instead of the eleven that 160 KB / 14.5 KB admitted.
+__device__ __forceinline__ double* wave_stage() { __shared__ double gsf_stage[64 * 10]; return gsf_stage; }
 // the pieces of the chunk whose last active lane is L, parked in `stage` (64 x 10 doubles of LDS, this wave's own) and picked up row by row
 __device__ __forceinline__ ChunkIn unpack_chunk(const ChunkWide& w, double* stage, const int lane, const int L)
 {
@@ -882,8 +887,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         // latency overlaps the scans below (the mask byte is compared at use time, never at load time)
         ChunkIn in;
         if constexpr (GSF_WIDE(SMALLBATCH)) {
-            __shared__ double gsf_in_stage[64 * 10];
-            in = unpack_chunk(nxt, gsf_in_stage, lane, L);
+            in = unpack_chunk(nxt, wave_stage(), lane, L);
             nxt = load_chunk_wide(tsb, posb, quatb, gpsb, valb, c0 + 64, lane, N);
         } else {
             in = nxt;
@@ -1118,7 +1122,7 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
             // slabs are contiguous (rows x 24 and rows x 32 bytes): the wave lays its rows out in LDS and stores the slabs as whole
             // 16-byte pieces, lane after lane -- four stores of a kilobyte each instead of seven strided ones.  A lone wave (C2) would
             // pay the LDS round trip on its critical path, so the small-batch build keeps the direct stores.
-            __shared__ double gsf_out_stage[64 * 7];
+            double* gsf_out_stage = wave_stage();                         // (the input stage of this iteration has been read back: unpack_chunk ends on a wait)
             typedef double gsf_d2 __attribute__((ext_vector_type(2), aligned(8)));
             gsf_out_stage[lane * 3] = o0; gsf_out_stage[lane * 3 + 1] = o1; gsf_out_stage[lane * 3 + 2] = o2;
             gsf_out_stage[192 + lane * 4] = qi.x; gsf_out_stage[192 + lane * 4 + 1] = qi.y; gsf_out_stage[192 + lane * 4 + 2] = qi.z; gsf_out_stage[192 + lane * 4 + 3] = qi.w;
