@@ -937,7 +937,7 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         # KITTI-04-length tracks in batches of other sizes: the headline batch (1 000 tracks = one wave per SIMD) is the latency-bound end of
         # the curve, the chip's throughput on 271-pose tracks is what the large batches show (same kernels, same bits per track)
         sweep = {}
-        for nb_ in (256, 1000, 2048, 4096, 16384, 100_000):
+        for nb_ in (256, 1000, 2048, 4096, 16384, 131_072):          # (131 072, not 100 000: the C3 launches have that grid, and the committed trace is keyed by kernel and grid)
             bt = B.TrajectoryBatch.synthetic(nb_, 271, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
             o = B.FusedPoses(bt.layout, nb_, 271, dev)
             ms_ = timed(lambda: B.fuse_pipeline_batch(bt, out=o, fit_rows=args.fit_rows), 50 if nb_ <= 16384 else 10)
