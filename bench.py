@@ -892,6 +892,7 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         launch()
         hout.copy_(out.buf, non_blocking=True)
     reps = 20 if Bn * N < 1e7 else 3
+    e2e()                                       # (untimed: the first transfer from / to a freshly pinned buffer maps it -- 90 ms once)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
