@@ -902,6 +902,31 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
     extra["pcie_inclusive"] = {"ms_per_step": dt * 1e3, "poses_per_s": Bn * N / dt, "bytes_over_pcie_per_step": Bn * N * ALG_BYTES_PER_POSE,
                                "GBps": Bn * N * ALG_BYTES_PER_POSE / dt / 1e9, "note": "pinned host buffers, H2D inputs + step + D2H fused poses, serial on one stream"}
     del hin, hout
+    if args.workload == "c2" and args.kernel == "pipeline" and batch.layout == B.LAYOUT_TRAJ_MAJOR:
+        # the HOST-POINTER entry of the boundary (include/gsf.h: gsf_fuse_pipeline_batch on plain host arrays -- staging arena + pinned mirror):
+        # what a cgo / JNI / ctypes caller with its data in host memory gets per call, PCIe included
+        import ctypes as C_
+        from gps_optimize_slam_amd import _lib as _l
+        hh = batch.host_traj_major()
+        arrs = [np.ascontiguousarray(hh[k]) for k in ("ts", "pos", "quat", "gps", "valid")]
+        Rh, th, sh = np.empty((Bn, 9)), np.empty((Bn, 3)), np.empty(Bn)
+        ph, qh, sth = np.empty((Bn, N, 3)), np.empty((Bn, N, 4)), np.empty(Bn, np.int32)
+        cfg_h = _l.EkfConfig.from_config(B.CONFIG)
+
+        def host_call():
+            _l.check(L.gsf_fuse_pipeline_batch(ctx.handle, 0, *[_l.hptr(a) for a in arrs], C_.byref(cfg_h), Bn, N, _l.hptr(Rh), _l.hptr(th), _l.hptr(sh),
+                                               _l.hptr(ph), _l.hptr(qh), _l.hptr(sth)))
+        try:
+            host_call(); host_call()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                host_call()
+            dth = (time.perf_counter() - t0) / 10
+            extra["host_pointer_entry"] = {"entry": "gsf_fuse_pipeline_batch (host arrays in, host arrays out)", "ms_per_call": dth * 1e3, "poses_per_s": Bn * N / dth,
+                                           "alg_bytes_through_the_call_GBps": Bn * N * ALG_BYTES_PER_POSE / dth / 1e9}
+        except Exception as e:
+            extra["host_pointer_entry"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        del arrs, ph, qh
     if args.workload == "c2":
         for name, (b3, n3, reps) in {"c3_100k_x_1k": (100_000, 1000, 5)}.items():
             ab = b3 * n3 * ALG_BYTES_PER_POSE
