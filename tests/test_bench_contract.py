@@ -135,3 +135,13 @@ def test_stream_rate_of_the_committed_aux_profile():
     rate, src = got
     assert 4.0e12 < rate < 8.0e12, rate
     assert src.endswith("_aux_by_kernel_and_grid.csv")
+
+
+def test_design_document_quotes_the_committed_profiles():
+    """the generated table and the chains paragraph are what tools/design_table.py / tools/design_chains.py produce from the
+    committed profiles (a profile refreshed without the document, or the other way round, fails here)."""
+    import subprocess
+    import sys
+    for tool in ("design_table.py", "design_chains.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "r04", "--check"], capture_output=True, text=True)
+        assert r.returncode == 0, (tool, r.stdout[-300:], r.stderr[-300:])
