@@ -644,8 +644,8 @@ def worker(args):
     # launches: at C2 a launch is ~20 us, so per-launch event pairs would make the loop host-bound and pad the gaps.
     def region():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()                          # (on an idle stream, right before the clock starts: the marker is for the kernel span, not part of the job)
         t0 = time.perf_counter()
-        ev[0].record()
         if graph is not None:
             graph.replay()
         else:
@@ -654,7 +654,9 @@ def worker(args):
         ev[1].record()
         if world > 1:
             collect()
-        ev[2].record()
+            ev[2].record()
+        else:
+            ev[2] = ev[1]
         torch.cuda.synchronize(); D.barrier(dev)
         return time.perf_counter() - t0, ev
     # The driver times K = 20 steps: a region of 0.4 ms, in which the HOST side of the bracket (event records, the graph launch, the wake-up
