@@ -533,6 +533,27 @@ def test_bench_two_ranks_self_spawned():
     assert abs(d["value"] - 2 * d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
 
 
+def test_bench_under_the_drivers_launcher_two_ranks():
+    """The driver's own N > 1 command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 --steps 20 --warmup 5` -- bench.py is then one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment),
+    rank 0 prints ONE JSON line, every rank exits 0 (gloo rehearsal on the one-GPU box; RCCL when each rank has its own GPU)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    port = 29600 + (os.getpid() % 300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["metric"].startswith("fused poses/sec")
+    assert d["collect"]["gathered_blocks_equal_rank_checksums"] is True
+    assert d["max_abs_pos_err_m"] < 1e-6 and d["status_bits_equal"] is True
+    assert abs(d["value"] - 2 * d["config"]["trajectories_per_gpu"] * d["config"]["poses_per_trajectory"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
 def test_bench_five_ranks_rehearsal_chunked_c5_leg():
     """More ranks than two on the one-GPU box (five: with the test process itself that is the six processes the box admits on the card):
     `bench.py --gpus 5` starts its ranks, every rank fuses its own id block with the real kernels, the collect and the chunked C5-shaped
