@@ -1036,20 +1036,30 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
         if (rts_mask != 0ull) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) dcorr[c] = xl[c] - (prev_lane(0.0, be[c]) + uu[c]);   // x_f[i] - x_p[i] (non-zero only where a fix was used)
-            const u64 later = rec_mask & ~bits(0, lane);                 // recoveries after this lane
-            const int rl = later != 0ull ? __ffsll((long long)later) - 1 : 0;
-            const bool in_run = active && !av && later != 0ull && (((rts_mask >> rl) & 1ull) != 0ull);
+            const int r1 = __ffsll((long long)rec_mask) - 1;             // first recovery of the chunk (rts_mask != 0, so there is one)
+            const bool one_rec = (rec_mask & (rec_mask - 1ull)) == 0ull; // ... and the only one: the usual chunk that closes an outage
+            // the recovery's correction and predicted variance as wave-uniform values: what every smoothed pose of a one-recovery chunk needs,
+            // and what the patch of the chunks already written needs (two v_readlane per value instead of a ds_bpermute pair per lane and value)
+            const double dr[3] = { lane_bcast(dcorr[0], r1), lane_bcast(dcorr[1], r1), lane_bcast(dcorr[2], r1) };
+            const double ipr[3] = { fast_rcp(lane_bcast(Pm[0], r1)), fast_rcp(lane_bcast(Pm[1], r1)), fast_rcp(lane_bcast(Pm[2], r1)) };
+            if (one_rec) {
+                const bool in_run = active && !av && lane < r1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double dr = shidx(dcorr[c], rl), pr = shidx(Pm[c], rl);
-                if (in_run) xo[c] = xl[c] + Pf[c] * fast_rcp(pr) * dr;
+                for (int c = 0; c < 3; ++c)
+                    if (in_run) xo[c] = xl[c] + Pf[c] * ipr[c] * dr[c];
+            } else {
+                const u64 later = rec_mask & ~bits(0, lane);             // recoveries after this lane
+                const int rl = later != 0ull ? __ffsll((long long)later) - 1 : 0;
+                const bool in_run = active && !av && later != 0ull && (((rts_mask >> rl) & 1ull) != 0ull);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double drl = shidx(dcorr[c], rl), pr = shidx(Pm[c], rl);
+                    if (in_run) xo[c] = xl[c] + Pf[c] * fast_rcp(pr) * drl;
+                }
             }
             // outage carried in from earlier chunks and closed here by an RTS recovery: fix the rows already written
             if (!c_prev_avail) {
-                const int r1 = __ffsll((long long)rec_mask) - 1;         // first recovery of the chunk closes the carried run
                 if ((rts_mask >> r1) & 1ull) {
-                    const double dr[3] = { lane_bcast(dcorr[0], r1), lane_bcast(dcorr[1], r1), lane_bcast(dcorr[2], r1) };
-                    const double ipr[3] = { fast_rcp(lane_bcast(Pm[0], r1)), fast_rcp(lane_bcast(Pm[1], r1)), fast_rcp(lane_bcast(Pm[2], r1)) };
                     // The last two chunks of the run are patched from a lane-private LDS ring (the rows as they were written and
                     // their P_f, kept by every chunk that ended inside the outage): no global read-modify-write, no stamps to
                     // re-scan.  Only a run that reaches further back than 128 poses takes the memory path for its older chunks.
