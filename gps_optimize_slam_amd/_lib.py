@@ -41,6 +41,44 @@ class EkfConfig(C.Structure):
         return c
 
 
+class PrefilterConfig(C.Structure):
+    """gsf_prefilter_config <- CONFIG['gps_filtering_ransac'] / CONFIG['ground_truth_gps_filtering'] (EKFGPSSLAM.py:39-48, :55-64)."""
+    _fields_ = [("enabled", C.c_int32), ("use_sliding_window", C.c_int32), ("window_duration_seconds", C.c_double), ("window_step_factor", C.c_double),
+                ("polynomial_degree", C.c_int32), ("min_samples", C.c_int32), ("residual_threshold_meters", C.c_double), ("max_trials", C.c_int32),
+                ("max_windows", C.c_int32), ("stop_probability", C.c_double)]
+
+    @classmethod
+    def from_config(cls, f, max_windows=0):
+        c = cls()
+        c.enabled, c.use_sliding_window = int(bool(f.get("enabled", False))), int(bool(f.get("use_sliding_window", False)))
+        c.window_duration_seconds, c.window_step_factor = float(f.get("window_duration_seconds", 0.0)), float(f.get("window_step_factor", 0.0))
+        c.polynomial_degree, c.min_samples = int(f["polynomial_degree"]), int(f["min_samples"])
+        c.residual_threshold_meters, c.max_trials = float(f["residual_threshold_meters"]), int(f["max_trials"])
+        c.max_windows, c.stop_probability = int(max_windows), 0.99
+        return c
+
+
+class RunConfig(C.Structure):
+    """gsf_run_config <- the whole CONFIG dict (EKFGPSSLAM.py:22-71): what main_process_gui reads between its step 1 and its step 6."""
+    _fields_ = [("ekf", EkfConfig), ("gps_filter", PrefilterConfig), ("sim3_residual_threshold", C.c_double), ("sim3_max_initial_duration", C.c_double),
+                ("max_gps_gap_threshold", C.c_double), ("eval_skip_seconds", C.c_double), ("sim3_min_samples", C.c_int32), ("sim3_max_trials", C.c_int32),
+                ("sim3_min_inliers_needed", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def from_config(cls, g, skip_seconds=5.0, max_windows=0):
+        c = cls()
+        c.ekf, c.gps_filter = EkfConfig.from_config(g), PrefilterConfig.from_config(g["gps_filtering_ransac"], max_windows)
+        r = g["sim3_ransac"]
+        c.sim3_residual_threshold, c.sim3_max_initial_duration = float(r["residual_threshold"]), float(r["max_initial_duration"])
+        c.max_gps_gap_threshold, c.eval_skip_seconds = float(g["time_alignment"]["max_gps_gap_threshold"]), float(skip_seconds)
+        c.sim3_min_samples, c.sim3_max_trials, c.sim3_min_inliers_needed = int(r["min_samples"]), int(r["max_trials"]), int(r["min_inliers_needed"])
+        return c
+
+
+RUN_GPS_EMPTY, RUN_GPS_FEW, RUN_PREFILTER_UNHANDLED, RUN_SIM3_FAILED, RUN_BAD_QUAT = 1, 2, 4, 8, 16      # run_status bits of gsf_run_fusion_batch_dev
+SIM3_FLAG_SATURATED = 256
+
+
 def library_path():
     return _SO
 
@@ -84,6 +122,8 @@ SIGNATURES = {
     "gsf_ransac_poly_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "gsf_gps_prefilter_auto_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(PrefilterConfig), _vp, _vp, _vp, _vp]),
+    "gsf_run_fusion_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, C.POINTER(RunConfig), _vp] + [_vp] * 18),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_windows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_windows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -97,6 +137,8 @@ SIGNATURES = {
     "gsf_mt19937_choice_bounded_batch_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "gsf_fuse_pipeline_robust_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
                                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsf_fuse_pipeline_robust_info_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
+                                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_fuse_pipeline_robust_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(EkfConfig), _i64, _i64, _i32, _f64, _i32, _i32, _vp,
                                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsf_apply_sim3_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

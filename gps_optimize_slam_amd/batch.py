@@ -126,6 +126,21 @@ class GeodeticBatch:
         self.slam_offsets = torch.arange(0, (self.B + 1) * self.N, self.N, dtype=torch.int64, device=ts.device)
 
     @classmethod
+    def from_host(cls, ts, pos, quat, logs, device="cuda"):
+        """B equal-length SLAM tracks (ts (B,N), pos (B,N,3), quat (B,N,4)) and their GNSS logs as the reference's loader reads them:
+        logs = list of B arrays (n_b, >= 4) with columns stamp, col 1, col 2, col 3 of the text file (read as lat, lon, alt; ref :258)."""
+        import numpy as np
+        ts = np.asarray(ts, dtype=np.float64)
+        Bn, N = ts.shape
+        counts = np.array([len(l) for l in logs], dtype=np.int64)
+        offs = np.zeros(Bn + 1, dtype=np.int64); offs[1:] = np.cumsum(counts)
+        allr = np.concatenate([np.asarray(l, dtype=np.float64)[:, :4] for l in logs]) if counts.sum() else np.zeros((0, 4))
+        f = dict(dtype=torch.float64, device=device)
+        return cls(Bn, N, torch.as_tensor(ts, **f).contiguous(), torch.as_tensor(np.asarray(pos, dtype=np.float64), **f).contiguous(),
+                   torch.as_tensor(np.asarray(quat, dtype=np.float64), **f).contiguous(), torch.as_tensor(offs, device=device),
+                   torch.as_tensor(np.ascontiguousarray(allr[:, 0]), **f), torch.as_tensor(np.ascontiguousarray(allr[:, 1:4]), **f), int(counts.max(initial=0)))
+
+    @classmethod
     def synthetic(cls, B, N, seed=20250523, traj0=0, device="cuda"):
         """Deterministic KITTI-04-shaped trajectories with a geodetic GNSS log around (49.0336 N, 8.3950 E)."""
         L, h = _lib.load(), context().handle
@@ -168,6 +183,45 @@ def fuse_from_geodetic(gb, config=None, out=None, fit_rows=FIT_ROWS_DEFAULT):
     check(L.gsf_fuse_pipeline_batch_dev(h, LAYOUT_TRAJ_MAJOR, _p(gb.ts), _p(gb.pos), _p(gb.quat), _p(aligned), _p(valid), C.byref(cfg), gb.B, gb.N,
                                         _p(R), _p(t), _p(s), _p(out.pos), _p(out.quat), _p(out.status)))
     return out, R, t, s, {"zone": zone, "south": south, "utm_rows": utm, "aligned": aligned, "valid": valid}
+
+
+class RunResult:
+    """What steps 1-6 of main_process_gui leave behind for B trajectories (run_fusion_batch): fused = FusedPoses, R / t / s, n_inliers,
+    inlier_mask, trial_info (deciding trial, trials drawn), zone / south, gps_utm (NaN rows where the loader drops the fix), gps_keep (fixes
+    that survive loader and pre-filter), aligned / valid (step 2), sim3_pos (step 4), err_stats (3, B, 4) = count / mean / median / RMSE of
+    raw SLAM, Sim3, EKF against the primary GPS (step 6), run_status (B,) = RUN_* bits (0 = the reference's run completes)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def run_fusion_batch(gb, mt_state, config=None, early_exit=True, skip_seconds=5.0, max_windows=0, want_mask=True):
+    """Steps 1-6 of main_process_gui (EKFGPSSLAM.py:959-1033) for the B trajectories of a GeodeticBatch as ONE device chain on torch's
+    current stream: load-side geodesy (:258-271) -> GPS RANSAC pre-filter with its windows walked on the device (:275, :136-247) ->
+    time alignment (:971) -> row choice (:973-998) -> robust Sim3 (:1002) -> apply (:1006) -> EKF + RTS (:1010) -> error metric (:1013-1033).
+    mt_state (B, 625): every trajectory's NumPy legacy generator (mt19937_seed / mt19937_from_numpy), advanced by the pre-filter's and
+    the fit's draws in the reference's order; early_exit as in fuse_pipeline_robust_batch (the pre-filter's draws are unaffected).
+    Returns a RunResult."""
+    g = config or CONFIG
+    ctx = context()
+    ctx.set_option("ransac_early_exit", 1 if early_exit else 0)
+    rc = _lib.RunConfig.from_config(g, skip_seconds, max_windows)
+    B, N, dev = gb.B, gb.N, gb.ts.device
+    f = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    total = int(gb.gps_t.numel())
+    out = FusedPoses(LAYOUT_TRAJ_MAJOR, B, N, dev)
+    r = RunResult(fused=out, R=torch.empty((B, 9), **f), t=torch.empty((B, 3), **f), s=torch.empty((B,), **f), n_inliers=torch.empty((B,), **i32),
+                  zone=torch.empty((B,), **i32), south=torch.empty((B,), **i32), gps_utm=torch.empty((total, 3), **f),
+                  gps_keep=torch.empty((total,), dtype=torch.uint8, device=dev), aligned=torch.empty((B, N, 3), **f),
+                  valid=torch.empty((B, N), dtype=torch.uint8, device=dev), sim3_pos=torch.empty((B, N, 3), **f), err_stats=torch.empty((3, B, 4), **f),
+                  run_status=torch.empty((B,), **i32), inlier_mask=torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None,
+                  trial_info=torch.empty((B, 2), **i32))
+    check(_lib.load().gsf_run_fusion_batch_dev(ctx.handle, _p(gb.ts), _p(gb.pos), _p(gb.quat), B, N, _p(gb.gps_t), _p(gb.gps_llh), _p(gb.gps_offsets), total,
+                                               int(gb.max_fixes), C.byref(rc), _p(mt_state), _p(r.R), _p(r.t), _p(r.s), _p(out.pos), _p(out.quat), _p(out.status),
+                                               _p(r.n_inliers), _p(r.zone), _p(r.south), _p(r.gps_utm), _p(r.gps_keep), _p(r.aligned), _p(r.valid), _p(r.sim3_pos),
+                                               _p(r.err_stats), _p(r.run_status), _p(r.inlier_mask), _p(r.trial_info)))
+    return r
 
 
 class FusedPoses:
@@ -257,26 +311,33 @@ def mt19937_choice_batch(state, n_population, trials, k):
     return idx
 
 
-def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask=True, fit_rows=FIT_ROWS_DEFAULT):
+def fuse_pipeline_robust_batch(batch, mt_state, config=None, out=None, want_mask=True, fit_rows=FIT_ROWS_DEFAULT, early_exit=True, return_info=False):
     """Steps 3-5 of main_process_gui with the reference's robust fit (EKFGPSSLAM.py:1002-1010): the rows main_process_gui picks
     (ref :973-998; fit_rows="all": every valid row) -> RANSAC hypotheses drawn on the device from each trajectory's legacy MT19937
-    stream -> inlier refit -> Sim3 of pose 0 -> EKF+RTS, one chain on torch's current stream.  Trajectory-major batches.  Returns
-    (FusedPoses, R, t, s, n_inliers (B,), inlier_mask (B, N) uint8 or None)."""
+    stream -> inlier refit -> Sim3 of pose 0 -> EKF+RTS, one chain on torch's current stream.  Trajectory-major batches.
+    early_exit (default on): a trajectory stops drawing at the first trial that counts every row of its fit -- the reference keeps a trial
+    only on a strictly larger count (ref :413), so R, t, s, mask, n_inliers and the fused poses are those of all max_trials, bit for bit;
+    only where `mt_state` is left differs (after fewer trials).  early_exit=False: every generator ends where np.random ends in the
+    reference.  Returns (FusedPoses, R, t, s, n_inliers (B,), inlier_mask (B, N) uint8 or None[, trial_info (B, 2) int32 = deciding trial,
+    trials drawn])."""
     if batch.layout != LAYOUT_TRAJ_MAJOR:
         raise ValueError("fuse_pipeline_robust_batch: trajectory-major batches only")
     g = config or CONFIG
-    context().set_sim3_rows(fit_rows, g)
+    ctx = context()
+    ctx.set_sim3_rows(fit_rows, g)
+    ctx.set_option("ransac_early_exit", 1 if early_exit else 0)
     cfg, r = EkfConfig.from_config(g), g["sim3_ransac"]
     out = out or FusedPoses(batch.layout, batch.B, batch.N, batch.ts.device)
     f = dict(dtype=torch.float64, device=batch.ts.device)
     R, t, s = torch.empty((batch.B, 9), **f), torch.empty((batch.B, 3), **f), torch.empty((batch.B,), **f)
     nin = torch.empty((batch.B,), dtype=torch.int32, device=batch.ts.device)
     mask = torch.empty((batch.B, batch.N), dtype=torch.uint8, device=batch.ts.device) if want_mask else None
-    check(_lib.load().gsf_fuse_pipeline_robust_batch_dev(context().handle, _p(batch.ts), _p(batch.pos), _p(batch.quat), _p(batch.gps), _p(batch.valid),
-                                                         C.byref(cfg), batch.B, batch.N, int(r["min_samples"]), float(r["residual_threshold"]),
-                                                         int(r["max_trials"]), int(r["min_inliers_needed"]), _p(mt_state), _p(R), _p(t), _p(s),
-                                                         _p(out.pos), _p(out.quat), _p(out.status), _p(nin), _p(mask)))
-    return out, R, t, s, nin, mask
+    info = torch.empty((batch.B, 2), dtype=torch.int32, device=batch.ts.device) if return_info else None
+    check(_lib.load().gsf_fuse_pipeline_robust_info_batch_dev(ctx.handle, _p(batch.ts), _p(batch.pos), _p(batch.quat), _p(batch.gps), _p(batch.valid),
+                                                              C.byref(cfg), batch.B, batch.N, int(r["min_samples"]), float(r["residual_threshold"]),
+                                                              int(r["max_trials"]), int(r["min_inliers_needed"]), _p(mt_state), _p(R), _p(t), _p(s),
+                                                              _p(out.pos), _p(out.quat), _p(out.status), _p(nin), _p(mask), _p(info)))
+    return (out, R, t, s, nin, mask, info) if return_info else (out, R, t, s, nin, mask)
 
 
 def sim3_fit_rows_batch(ts, gps, valid, config=None, offsets=None):

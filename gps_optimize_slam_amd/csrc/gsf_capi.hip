@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 
 #include <vector>
 
@@ -62,6 +63,32 @@ int ensure_k2b_scratch(gsf_ctx* ctx, size_t bytes)
     }
     GSF_HIP(hipMalloc(&ctx->k2b_scratch, bytes + bytes / 4));
     ctx->k2b_scratch_bytes = bytes + bytes / 4;
+    return GSF_OK;
+}
+
+int ensure_run_scratch(gsf_ctx* ctx, size_t bytes)
+{
+    if (ctx->run_scratch_bytes >= bytes) return GSF_OK;
+    if (ctx->run_scratch) {
+        GSF_HIP(hipStreamSynchronize(ctx->stream));
+        GSF_HIP(hipFree(ctx->run_scratch));
+        ctx->run_scratch = nullptr; ctx->run_scratch_bytes = 0;
+    }
+    GSF_HIP(hipMalloc(&ctx->run_scratch, bytes + bytes / 4));
+    ctx->run_scratch_bytes = bytes + bytes / 4;
+    return GSF_OK;
+}
+
+int ensure_rows_scratch(gsf_ctx* ctx, size_t bytes)
+{
+    if (ctx->rows_scratch_bytes >= bytes) return GSF_OK;
+    if (ctx->rows_scratch) {
+        GSF_HIP(hipStreamSynchronize(ctx->stream));
+        GSF_HIP(hipFree(ctx->rows_scratch));
+        ctx->rows_scratch = nullptr; ctx->rows_scratch_bytes = 0;
+    }
+    GSF_HIP(hipMalloc(&ctx->rows_scratch, bytes + bytes / 4));
+    ctx->rows_scratch_bytes = bytes + bytes / 4;
     return GSF_OK;
 }
 
@@ -164,13 +191,10 @@ extern "C" {
 // the Makefile's fall-back path cannot ship unnoticed (bench.py prints this string).
 const char* gsf_version(void)
 {
-    static char buf[640];
-    static bool done = false;
-    if (!done) {
-        snprintf(buf, sizeof buf, "gsf 0.4.0 (gfx950, fp64) | %s | %s | %s", gsf::wave_small_build_info(), gsf::wave_big_build_info(), gsf::wave_block_build_info());
-        done = true;
-    }
-    return buf;
+    // a function-local static is initialised once, also under concurrent first calls (C++11)
+    static const std::string v = std::string("gsf 0.5.0 (gfx950, fp64) | ") + gsf::wave_small_build_info() + " | " + gsf::wave_big_build_info() + " | " +
+                                 gsf::wave_block_build_info();
+    return v.c_str();
 }
 int gsf_abi_version(void) { return GSF_ABI_VERSION; }
 
@@ -201,9 +225,12 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     GSF_HIP(hipSetDevice(device_id));
     gsf_ctx* c = new gsf_ctx();
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
-    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr; c->k2b_screen = 1; c->k2b_scratch = nullptr; c->k2b_scratch_bytes = 0;
+    c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->rows_scratch = nullptr; c->rows_scratch_bytes = 0; c->run_scratch = nullptr; c->run_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr; c->k2b_screen = 1; c->k2b_scratch = nullptr; c->k2b_scratch_bytes = 0;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
-    c->fit_rows = gsf::FitRows{ 0, 4, 5.0, 180.0 };                        // every valid row; the numbers are the reference's CONFIG defaults (:34, :53, :37)
+    c->ransac_early_exit = 0; c->ransac_probe_trials = 64;
+    // the fused chains fit the rows main_process_gui hands to its fit (ref :973-998) under the reference's CONFIG defaults (:34, :53, :37)
+    // unless the caller says otherwise (gsf_set_sim3_rows): a raw C caller of gsf_fuse_pipeline_* gets steps 3-5 as the reference runs them
+    c->fit_rows = gsf::FitRows{ 1, 4, 5.0, 180.0 };
     if (owns) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail_hip(e, "hipStreamCreateWithFlags"); }
@@ -235,6 +262,8 @@ void gsf_destroy(gsf_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->rng_scratch) (void)hipFree(ctx->rng_scratch);
+    if (ctx->rows_scratch) (void)hipFree(ctx->rows_scratch);
+    if (ctx->run_scratch) (void)hipFree(ctx->run_scratch);
     if (ctx->small_scratch) (void)hipFree(ctx->small_scratch);
     if (ctx->k2b_scratch) (void)hipFree(ctx->k2b_scratch);
     if (ctx->stage) (void)hipFree(ctx->stage);
@@ -253,6 +282,8 @@ int gsf_trim(gsf_ctx* ctx)
     if (ctx->scratch) { GSF_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
     if (ctx->rng_scratch) { GSF_HIP(hipFree(ctx->rng_scratch)); ctx->rng_scratch = nullptr; ctx->rng_scratch_bytes = 0; }
     if (ctx->k2b_scratch) { GSF_HIP(hipFree(ctx->k2b_scratch)); ctx->k2b_scratch = nullptr; ctx->k2b_scratch_bytes = 0; }
+    if (ctx->rows_scratch) { GSF_HIP(hipFree(ctx->rows_scratch)); ctx->rows_scratch = nullptr; ctx->rows_scratch_bytes = 0; }
+    if (ctx->run_scratch) { GSF_HIP(hipFree(ctx->run_scratch)); ctx->run_scratch = nullptr; ctx->run_scratch_bytes = 0; }
     if (ctx->stage) { GSF_HIP(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
     if (ctx->pinned) { GSF_HIP(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
     return GSF_OK;
@@ -284,6 +315,14 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     if (strcmp(key, "tape_draws") == 0) {
         if (value < -1 || value > 2 || value == 1) { set_error("gsf_set_option: tape_draws must be -1 (automatic: a few streams are drawn chip-wide), 0 (always one wave per stream) or 2 (tests: a tape cut short, so that the one-wave kernel takes over)"); return GSF_ERR_INVALID_ARG; }
         ctx->tape_draws = (int)value; return GSF_OK;
+    }
+    if (strcmp(key, "ransac_early_exit") == 0) {
+        if (value < 0 || value > 1) { set_error("gsf_set_option: ransac_early_exit must be 0 (every trajectory draws all max_trials: the generator ends where the reference leaves it) or 1 (a trajectory stops at the first trial that counts every row: same R, t, s, mask and poses)"); return GSF_ERR_INVALID_ARG; }
+        ctx->ransac_early_exit = (int)value; return GSF_OK;
+    }
+    if (strcmp(key, "ransac_probe_trials") == 0) {
+        if (value < 1 || value > (1 << 20)) { set_error("gsf_set_option: ransac_probe_trials must be in [1, 2^20]"); return GSF_ERR_INVALID_ARG; }
+        ctx->ransac_probe_trials = (int)value; return GSF_OK;
     }
     if (strcmp(key, "duo_kernel") == 0) {
         if (value < -1 || value > 1) { set_error("gsf_set_option: duo_kernel must be -1 (automatic), 0 (one wave) or 1 (two-wave blocks)"); return GSF_ERR_INVALID_ARG; }

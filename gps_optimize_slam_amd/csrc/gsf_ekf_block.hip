@@ -74,6 +74,7 @@ __device__ __forceinline__ bool quat_norm_ok(const Quat& q)
 struct BlockCtx {
     const double* __restrict__ tsb; const double* __restrict__ posb; const double* __restrict__ quatb; const double* __restrict__ gpsb;
     const uint8_t* __restrict__ valb;
+    const uint8_t* __restrict__ rselb; // pipeline under the reference's row choice (gsf_set_sim3_rows mode 1): the rows of the fit, marked by sim3_rows_kernel; else NULL
     double* __restrict__ pob; double* __restrict__ qob;
     int64_t N; int lane, C;            // C = chunks of the track
     int same1, same2;                 // axis c repeats axis same_c (-1: scans of its own)
@@ -91,8 +92,9 @@ struct Chunk {
     double c_t; Vec3 c_po; Quat c_qraw; double cz0, cz1, cz2; uint32_t c_vraw;
     // phase A results
     Vec3 d, z; Quat r; double dt;
-    bool avail, av, recovers, both_ok, c_prev_avail, open_end, okf;
+    bool avail, av, recovers, both_ok, c_prev_avail, open_end, okf, fitrow;
     u64 a_mask, start_mask, rec_mask, f_mask, rts_mask, okf_mask;
+    uint32_t rsel;
     Moebius M0, M1, M2;
     // after barrier 1
     double Pf[3], Pm[3], kg[3], wgt;
@@ -115,6 +117,7 @@ struct Chunk {
         c_qraw = Quat{ k.quatb[ip * 4], k.quatb[ip * 4 + 1], k.quatb[ip * 4 + 2], k.quatb[ip * 4 + 3] };
         cz0 = k.gpsb[ip * 3]; cz1 = k.gpsb[ip * 3 + 1]; cz2 = k.gpsb[ip * 3 + 2];
         c_vraw = k.valb[ip];
+        rsel = (PIPELINE && k.rselb) ? k.rselb[active ? i : 0] : 1u;    // ref :973-998, decided by the launcher's pre-pass
     }
 
     // everything that needs no other chunk: ballots of the outage structure, variance maps with the identity carry
@@ -142,8 +145,9 @@ struct Chunk {
         const bool zfin = !(isnan(z.x) || isnan(z.y) || isnan(z.z));
         avail = stepping && vraw && zfin;                                // ref :867-869
         av = is_init ? vraw : avail;                                     // pose 0: raw mask, ref :848
-        okf = active && vraw && zfin;                                    // rows of the fit (ref :430-438)
+        okf = active && vraw && zfin;                                    // rows with a usable fix
         okf_mask = __ballot(okf);
+        fitrow = okf && rsel != 0;                                       // rows of the fit (ref :430-438; under mode 1 the reference's choice of them)
         a_mask = __ballot(active && av);
         const bool ap = (lane == 0) ? (is_init ? true : c_prev_avail) : (((a_mask >> (lane - 1)) & 1ull) != 0ull);
         const bool starts = active && !av && ap;                         // ref :875-877 (pose 0: :861)
@@ -185,12 +189,13 @@ struct Chunk {
                                             const double bs0, const double bs1, const double bs2)
     {
         const Vec3 p = in.p;
-        const double a0 = okf ? p.x - as0 : 0.0, a1 = okf ? p.y - as1 : 0.0, a2 = okf ? p.z - as2 : 0.0;
-        const double b0 = okf ? z.x - bs0 : 0.0, b1 = okf ? z.y - bs1 : 0.0, b2 = okf ? z.z - bs2 : 0.0;
+        const double a0 = fitrow ? p.x - as0 : 0.0, a1 = fitrow ? p.y - as1 : 0.0, a2 = fitrow ? p.z - as2 : 0.0;
+        const double b0 = fitrow ? z.x - bs0 : 0.0, b1 = fitrow ? z.y - bs1 : 0.0, b2 = fitrow ? z.z - bs2 : 0.0;
         const double zrow = row_sums16_transposed(a0, a1, a2, b0, b1, b2, a0 * a0 + a1 * a1 + a2 * a2, a0 * b0, a0 * b1, a0 * b2,
                                                   a1 * b0, a1 * b1, a1 * b2, a2 * b0, a2 * b1, a2 * b2, k.lane);
         sh.mom[vc][k.lane] = zrow;
-        if (k.lane == 0) sh.cnt[vc] = __popcll(okf_mask);
+        const u64 fit_mask = __ballot(fitrow);
+        if (k.lane == 0) sh.cnt[vc] = __popcll(fit_mask);
     }
 
     // after barrier 1: outage state carried in, recovery decisions, carry-in variances, gains
@@ -377,7 +382,8 @@ struct Chunk {
 
 // MAXT threads at most; OCC = waves per SIMD the register allocation must allow
 template <bool PIPELINE, int AXMODE, int MAXT, int OCC, bool INLINE_COLD>
-__global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfConfig cfg)
+__global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfConfig cfg, const uint8_t* __restrict__ rowsel,
+                                                              const int32_t* __restrict__ rows_status)
 {
     __shared__ BlockShared sh;
 #ifdef GSF_BLOCK_TIMING
@@ -396,6 +402,8 @@ __global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfCon
     BlockCtx k;
     k.tsb = a.ts + base; k.posb = a.pos + base * 3; k.quatb = a.quat + base * 4; k.gpsb = a.gps + base * 3; k.valb = a.valid + base;
     k.pob = a.pos_out + base * 3; k.qob = a.quat_out + base * 4;
+    k.rselb = (PIPELINE && rowsel) ? rowsel + base : nullptr;
+    const int32_t rows_flag = (PIPELINE && rows_status) ? rows_status[b] : 0;   // SIM3_FLAG_FEW_ROWS / _ROWS_ALL / _ROWS_SEGMENT
     k.N = N; k.lane = lane; k.C = W;
     k.same1 = -1; k.same2 = -1;
     if (AXMODE == 1) k.same1 = 0;
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfCon
             const double a0 = k.posb[0], a1 = k.posb[1], a2 = k.posb[2];  // (read again: cheaper than keeping them in registers)
             double Rb[9], tb[3], sb = NAN;
             fit = SIM3_NONE;
-            if (n >= 3.0) {                                              // ref :430
+            if (n >= 3.0 && !(rows_flag & SIM3_FLAG_FEW_ROWS)) {          // ref :430 (and :975 / :997: the reference raised before it got here)
                 const Sums16 S = sums16_finish(zs);
                 const double rn = fast_rcp(n);
                 const double ma[3] = { S.v[0] * rn, S.v[1] * rn, S.v[2] * rn };
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfCon
                 k.pob[c1.i * 3] = NAN; k.pob[c1.i * 3 + 1] = NAN; k.pob[c1.i * 3 + 2] = NAN;
                 k.qob[c1.i * 4] = NAN; k.qob[c1.i * 4 + 1] = NAN; k.qob[c1.i * 4 + 2] = NAN; k.qob[c1.i * 4 + 3] = NAN;
             }
-            if (threadIdx.x == 0 && a.status) a.status[b] = (fit == SIM3_NONE ? (SIM3_NONE << 8) : 0) | (r0ok ? 0 : ST_BAD_QUAT);
+            if (threadIdx.x == 0 && a.status) a.status[b] = (fit == SIM3_NONE ? ((SIM3_NONE | (rows_flag & SIM3_FLAG_FEW_ROWS)) << 8) : 0) | (r0ok ? 0 : ST_BAD_QUAT);
             return;
         }
         p0 = Vec3{ sh.fitv[0], sh.fitv[1], sh.fitv[2] };
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(MAXT, OCC) void ekf_block_kernel(WaveArgs a, EkfCon
     if (w == 0 && lane == 0 && a.status) {
         int32_t st = 0;
         for (int v = 0; v < k.C; ++v) st |= sh.status[v];
-        a.status[b] = st | (PIPELINE ? (fit << 8) : 0);
+        a.status[b] = st | (PIPELINE ? ((fit | rows_flag) << 8) : 0);
     }
     if (cross_rts) block_barrier();                                      // ---- barrier 4 (block-uniform)
     BSTAMP(9);
@@ -598,7 +606,18 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
                     !(k.P0[2] == k.P0[0] && k.Qps[2] == k.Qps[0] && k.Rm[2] == k.Rm[0]);
     const int W = (int)((N + 63) / 64);
     const dim3 grid((unsigned)B), block((unsigned)(W * 64));
-#define GSF_LAUNCH_BLOCK(P_, X_, T_, O_, I_) hipLaunchKernelGGL((ekf_block_kernel<P_, X_, T_, O_, I_>), grid, block, 0, ctx->stream, a, k)
+    // the fit under the reference's row choice (gsf_set_sim3_rows mode 1, ref :973-998): the rows are marked by a launch of their own (the
+    // rule is a serial walk over the valid rows of a track; here every chunk has its own wave) and the moments take the marked rows only
+    const uint8_t* rowsel = nullptr; const int32_t* rows_status = nullptr;
+    if (pipeline && ctx->fit_rows.mode != 0) {
+        const size_t P = (size_t)B * (size_t)N, o_st = (P + 255) & ~(size_t)255, o_n = o_st + (((size_t)B * 4 + 255) & ~(size_t)255);
+        int rc = ensure_rows_scratch(ctx, o_n + (size_t)B * 4);
+        if (rc) return rc;
+        char* w = (char*)ctx->rows_scratch;
+        if ((rc = launch_sim3_rows(ctx, ts, gps, valid, nullptr, B, N, ctx->fit_rows, (uint8_t*)w, (int32_t*)(w + o_n), (int32_t*)(w + o_st)))) return rc;
+        rowsel = (const uint8_t*)w; rows_status = (const int32_t*)(w + o_st);
+    }
+#define GSF_LAUNCH_BLOCK(P_, X_, T_, O_, I_) hipLaunchKernelGGL((ekf_block_kernel<P_, X_, T_, O_, I_>), grid, block, 0, ctx->stream, a, k, rowsel, rows_status)
 #define GSF_LAUNCH_BLOCK_T(P_, X_) do { \
         if (W <= 5) GSF_LAUNCH_BLOCK(P_, X_, 320, 5, true); \
         else if (W <= 8) GSF_LAUNCH_BLOCK(P_, X_, 512, 4, true); \

@@ -73,8 +73,8 @@ int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double*
     GSF_REQUIRE(B <= 0x7fffffff, "B too large for one launch");
     // tracks of 65..1024 poses: one workgroup per trajectory, one wave per chunk (gsf_ekf_block.hip).  The choice depends on N and the
     // layout only, never on B, so a shard of a batch produces the same bits as the whole batch.
-    // (its fit is a cross-wave reduction over ALL valid rows: a pipeline call under the reference's row choice stays with the wave kernel)
-    if (ctx->block_kernel == 1 && ekf_block_applies(N, offsets) && !(pipeline && ctx->fit_rows.mode != 0))
+    // (under the reference's row choice its launcher marks the rows of the fit with a launch of sim3_rows_kernel first)
+    if (ctx->block_kernel == 1 && ekf_block_applies(N, offsets))
         return launch_ekf_block(ctx, pipeline, ts, pos, quat, gps, valid, init_pos, init_quat, cfg, B, N, R, t, s, pos_out, quat_out, status);
     WaveArgs a{ ts, pos, quat, gps, valid, init_pos, init_quat, R, t, s, pos_out, quat_out, status, B, N, offsets, pipeline ? ctx->fit_rows : FitRows{ 0, 0, 0.0, 0.0 } };
     const EkfConfig k = to_core(cfg);

@@ -288,11 +288,19 @@ __device__ __forceinline__ void score_trial(const double* __restrict__ tp, const
 // either AND the axis mask into the window mask or -- no consensus set: the reference's exception -- drop the window and skip its
 // remaining axes (they consume nothing).  keep[] = OR over the successful windows.  One wave per log.
 constexpr int CH_MAX_TRIALS = 1024;
+// Where the windows of a log come from.  mode 0: the caller lists them (win_rows / win_offsets: the host walked the stamps).  mode 1: the
+// kernel walks the stamps itself the way the reference does (ref :199-234: windows [w0, w0 + width) advanced by `stride`, one extra tail
+// window ending just past the last stamp; a window with fewer than `need` rows is skipped) -- sorted stamps only, so that every window is
+// one row range (an unsorted log is flagged 3 and left to the host route).  mode 2: one window = the whole log (ref :148-182).
+// Modes 1 / 2 also take the reference's early-outs: filtering disabled -> every row kept, nothing drawn (:139-141); fewer than `need` rows
+// -> the same (:144-146).
+struct WinGen { int32_t mode, need; double width, stride; int32_t enabled, max_windows; };
 __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* __restrict__ t, const double* __restrict__ pos, const int64_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ counts,
                                                                  const int32_t* __restrict__ win_rows, const int64_t* __restrict__ win_offsets,
                                                                  int max_trials, int ms, int degree, double thr, double stop_prob, int jseq_elems,
                                                                  uint32_t* __restrict__ state, uint8_t* __restrict__ keep, int32_t* __restrict__ win_status,
-                                                                 int32_t* __restrict__ log_status)
+                                                                 int32_t* __restrict__ log_status, WinGen gen, int32_t* __restrict__ log_info)
 {
     __shared__ uint32_t mt[MT_N + 1];
     __shared__ uint32_t snap[MT_N + 1];
@@ -306,21 +314,27 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t r_base = offsets[b];
-    const int n_log = (int)(offsets[b + 1] - r_base);
+    const int n_log = counts ? counts[b] : (int)(offsets[b + 1] - r_base);   // (counts: logs in fixed-stride slots, e.g. after the loader's rows were compacted)
     uint32_t* st = state + b * MT_STATE_WORDS;
+    if (gen.mode != 0 && (gen.enabled == 0 || n_log < gen.need)) {        // ref :139-146: the log passes unfiltered, the generator is not touched
+        for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 1;
+        if (lane == 0) { log_status[b] = 0; if (log_info) { log_info[b * 2] = 0; log_info[b * 2 + 1] = 0; } }
+        return;
+    }
     for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
     int pos_mt = (int)st[MT_N];
     for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 0;
     __syncthreads();
     int lstat = 0;
-    for (int64_t w = win_offsets[b]; w < win_offsets[b + 1]; ++w) {
-        const int r0 = win_rows[w * 2], r1 = win_rows[w * 2 + 1], n = r1 - r0;
+    // one window (rows r0 .. r1-1 of the log): 0 ok / 1 no consensus set / 2 fewer rows than min_samples (not processed) / 3 not handled
+    auto run_window = [&](const int r0, const int r1) -> int {
+        const int n = r1 - r0;
         int wstat = 0;
-        if (n < ms || r0 < 0 || r1 > n_log) { if (lane == 0) win_status[w] = 2; continue; }           // ref :209: too few rows, window not processed
+        if (n < ms || r0 < 0 || r1 > n_log) return 2;                     // ref :209: too few rows, window not processed
         // scikit-learn's sampler takes the permutation route only for 0.01 < k/n < 0.99; other ratios (tracking selection / reservoir
         // sampling) are not restated on the device: the log is flagged and left to the host-drawn path
         const double ratio = (double)ms / (double)n;
-        if (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems) { lstat = 2; if (lane == 0) win_status[w] = 3; break; }
+        if (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems) { lstat = 2; return 3; }
         const double* tp = t + r_base + r0;
         // window mask lives in keep[] itself as bit 1 (AND over axes), folded into bit 0 (OR over windows) when the window succeeds
         for (int i = lane; i < n; i += 64) keep[r_base + r0 + i] |= 2;
@@ -407,11 +421,62 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             const uint8_t v = keep[r_base + r0 + i];
             keep[r_base + r0 + i] = (uint8_t)((v & 1u) | ((wstat == 0 && (v & 2u)) ? 1u : 0u));
         }
-        if (lane == 0) win_status[w] = wstat;
         __syncthreads();
+        return wstat;
+    };
+    int processed = 0, succeeded = 0;
+    if (gen.mode == 0) {
+        for (int64_t w = win_offsets[b]; w < win_offsets[b + 1]; ++w) {
+            const int ws = run_window(win_rows[w * 2], win_rows[w * 2 + 1]);
+            if (lane == 0) win_status[w] = ws;
+            if (ws == 3) break;
+            processed += ws != 2; succeeded += ws == 0;
+        }
+    } else if (gen.mode == 2) {                                           // ref :148-182: one fit over the whole log; if it raises the log passes unfiltered
+        const int ws = run_window(0, n_log);
+        processed = 1; succeeded = ws == 0;
+        if (ws == 1) { for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 1; }
+    } else {
+        // ref :196-234.  Stamps must be sorted (every window one row range): checked first.
+        const double* tl = t + r_base;
+        bool sorted = true;
+        for (int i = lane; i + 1 < n_log; i += 64) sorted = sorted && tl[i] <= tl[i + 1];
+        if (__ballot(!sorted) != 0ull) lstat = 3;
+        else {
+            const double t_first = tl[0], t_last = tl[n_log - 1];
+            // first row with stamp >= x / > x (wave-parallel count of the rows below: the stamps are sorted)
+            auto rows_below = [&](const double x, const bool strict) -> int {
+                int c = 0;
+                for (int i0 = 0; i0 < n_log; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool below = i < n_log && (strict ? tl[i] < x : tl[i] <= x);
+                    const int k = __popcll(__ballot(below));
+                    c += k;
+                    if (k < 64) break;
+                }
+                return c;
+            };
+            double w0 = t_first;
+            int visited = 0;
+            while (w0 < t_last) {                                         // :200
+                if (++visited > gen.max_windows) { lstat = 3; break; }
+                const double w1 = w0 + gen.width;                         // :201
+                const int r0 = rows_below(w0, true), r1 = rows_below(w1, true);   // rows with w0 <= t < w1 (:202)
+                if (r1 - r0 >= gen.need) {                                // :204
+                    const int ws = run_window(r0, r1);
+                    if (ws == 3) break;
+                    processed += 1; succeeded += ws == 0;
+                }
+                if (gen.stride <= 1e-6) {                                 // :230-232
+                    const int nx = rows_below(w0, false);                 // first row with t > w0
+                    if (nx < n_log) w0 = tl[nx]; else break;
+                } else w0 += gen.stride;                                  // :233
+                if (w0 >= t_last && t_last >= w1) w0 = fmax(t_first, t_last - gen.width + 1e-6);   // :234-235
+            }
+        }
     }
     for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
-    if (lane == 0) { st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; }
+    if (lane == 0) { st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; if (log_info) { log_info[b * 2] = processed; log_info[b * 2 + 1] = succeeded; } }
 }
 
 }  // namespace
@@ -449,6 +514,18 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
     return GSF_OK;
 }
 
+// LDS of the chain kernel (40 KB dynamic next to 23 KB of static arrays): the sample sets of one window-axis, then the swap partners of as
+// many trials as the rest allows (at least one trial's worth)
+static int chain_lds(int32_t max_trials, int32_t min_samples, int32_t max_window_rows, int& jseq_elems, size_t& lds)
+{
+    const size_t idx_bytes = (size_t)max_trials * (size_t)min_samples * 4;
+    if (idx_bytes + 2 * (size_t)max_window_rows + 4 > 40 * 1024) return 1;
+    int tb = (int)((40 * 1024 - idx_bytes - 4) / 2 / (size_t)max_window_rows); if (tb > 64) tb = 64;
+    jseq_elems = tb * max_window_rows;
+    lds = (size_t)((jseq_elems + 1) & ~1) * 2 + idx_bytes;
+    return 0;
+}
+
 int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, int64_t B, const int32_t* win_rows,
                                 const int64_t* win_offsets, int32_t max_window_rows, int32_t max_trials, int32_t min_samples, int32_t degree,
                                 double residual_threshold, double stop_probability, uint32_t* mt_state, uint8_t* keep, int32_t* win_status,
@@ -463,17 +540,50 @@ int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos
     if (B == 0) return GSF_OK;
     GSF_REQUIRE(t && pos, "NULL rows");
     GSF_HIP(hipSetDevice(ctx->device));
-    // dynamic LDS (40 KB next to 23 KB of static arrays): the sample sets of one window-axis, then the swap partners of as many trials
-    // as the rest allows (at least one trial's worth)
-    const size_t idx_bytes = (size_t)max_trials * (size_t)min_samples * 4;
-    GSF_REQUIRE(idx_bytes + 2 * (size_t)max_window_rows + 4 <= 40 * 1024, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
-    int tb = (int)((40 * 1024 - idx_bytes - 4) / 2 / (size_t)max_window_rows); if (tb > 64) tb = 64;
-    const int jseq_elems = tb * max_window_rows;
-    const size_t lds = (size_t)((jseq_elems + 1) & ~1) * 2 + idx_bytes;
-    hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, win_rows, win_offsets, (int)max_trials,
-                       (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status);
+    int jseq_elems = 0; size_t lds = 0;
+    GSF_REQUIRE(chain_lds(max_trials, min_samples, max_window_rows, jseq_elems, lds) == 0, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
+    hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, (const int32_t*)nullptr, win_rows, win_offsets,
+                       (int)max_trials, (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status,
+                       WinGen{ 0, min_samples, 0.0, 0.0, 1, 0 }, (int32_t*)nullptr);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
+}
+
+}  // extern "C"
+
+namespace gsf {
+// the chain with the windows found ON THE DEVICE from the stamps (filter_gps_outliers_ransac as a whole, ref :136-247); counts (may be
+// NULL): log b = rows offsets[b] .. offsets[b] + counts[b]
+int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, const int32_t* counts, int64_t B,
+                              int32_t max_log_rows, const gsf_prefilter_config* f, uint32_t* mt_state, uint8_t* keep, int32_t* log_status, int32_t* log_info)
+{
+    GSF_REQUIRE(f->max_trials >= 1 && f->max_trials <= CH_MAX_TRIALS, "pre-filter max_trials must be in [1,1024]");
+    GSF_REQUIRE(f->min_samples >= 1 && f->min_samples <= RP_MAX_SAMPLES, "pre-filter min_samples must be in [1,16]");
+    GSF_REQUIRE(f->polynomial_degree >= 1 && f->polynomial_degree <= RP_MAX_DEGREE, "pre-filter polynomial degree must be in [1,3]");
+    GSF_REQUIRE(max_log_rows >= 1 && max_log_rows <= 14000, "a log must hold 1 .. 14000 fixes for the device pre-filter");
+    int jseq_elems = 0; size_t lds = 0;
+    GSF_REQUIRE(chain_lds(f->max_trials, f->min_samples, max_log_rows, jseq_elems, lds) == 0, "max_trials x min_samples / log length exceed the device sampler's LDS budget");
+    const WinGen gen{ f->use_sliding_window ? 1 : 2, f->min_samples, f->window_duration_seconds, f->window_duration_seconds * f->window_step_factor,
+                      f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096 };
+    hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, counts, (const int32_t*)nullptr,
+                       (const int64_t*)nullptr, (int)f->max_trials, (int)f->min_samples, (int)f->polynomial_degree, f->residual_threshold_meters,
+                       f->stop_probability > 0.0 ? f->stop_probability : 0.99, jseq_elems, mt_state, keep, (int32_t*)nullptr, log_status, gen, log_info);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+}  // namespace gsf
+
+extern "C" {
+
+int gsf_gps_prefilter_auto_dev(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, int64_t B, int32_t max_log_rows,
+                               const gsf_prefilter_config* filter, uint32_t* mt_state, uint8_t* keep, int32_t* log_status, int32_t* log_info)
+{
+    GSF_REQUIRE(ctx && offsets && filter && mt_state && keep && log_status, "NULL argument");
+    GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
+    if (B == 0) return GSF_OK;
+    GSF_REQUIRE(t && pos, "NULL rows");
+    GSF_HIP(hipSetDevice(ctx->device));
+    return launch_gps_prefilter_auto(ctx, t, pos, offsets, nullptr, B, max_log_rows, filter, mt_state, keep, log_status, log_info);
 }
 
 int gsf_gps_prefilter_chain(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, int64_t B, const int32_t* win_rows,

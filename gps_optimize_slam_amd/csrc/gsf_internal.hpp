@@ -27,11 +27,17 @@ struct gsf_ctx {
     size_t k2b_scratch_bytes;
     void* rng_scratch;
     size_t rng_scratch_bytes;
+    void* run_scratch;     // temporaries of gsf_run_fusion_batch_dev (its stages use `scratch` themselves), grow-only
+    size_t run_scratch_bytes;
+    void* rows_scratch;    // row mask + flags of the Sim3 row choice for the kernels that take it as a pre-pass (gsf_ekf_block.hip), grow-only
+    size_t rows_scratch_bytes;
     int k2b_screen;        // K2b residual counts screened in packed single precision, exact re-check in the band (gsf_set_option "k2b_screen"): 1 default, 0 all double
     int tape_draws;        // chip-wide draws for a few streams (gsf_set_option "tape_draws"): -1 automatic, 0 never, 2 tests (tape cut short)
     int ekf_variant;       // reserved tuning knob (gsf_set_option "ekf_variant"); 0 = default
     int synth_variant;     // synthetic workload (gsf_set_option "synth_variant"): 0 = white SLAM noise (default), 1 = SURVEY 8d's random-walk drift
     int block_kernel;      // workgroup-per-trajectory kernel for 64 < N <= 1024 (gsf_set_option "block_kernel"): -1 automatic, 0 never, 1 always
+    int ransac_early_exit; // robust chain: stop a trajectory's trials at the first one that counts every row (gsf_set_option "ransac_early_exit"): 0 default, 1 on
+    int ransac_probe_trials; // ... trials the early-exit probe draws and scores itself before the wide kernels take the rest (gsf_set_option "ransac_probe_trials")
     int duo_kernel;        // two-wave pipeline kernel for small batches (gsf_set_option "duo_kernel"): -1 automatic, 0 never, 1 always
     gsf::FitRows fit_rows; // rows of the fused chains' Sim3 fit (gsf_set_sim3_rows); mode 0 = all valid rows
     int64_t lane_min_traj; // time-major batches with fewer trajectories are transposed and run by the wave kernel (gsf_set_option "lane_min_traj")
@@ -79,6 +85,8 @@ const char* wave_block_build_info();
 int ensure_scratch(gsf_ctx* ctx, size_t bytes);
 int ensure_rng_scratch(gsf_ctx* ctx, size_t bytes);
 int ensure_k2b_scratch(gsf_ctx* ctx, size_t bytes);
+int ensure_rows_scratch(gsf_ctx* ctx, size_t bytes);
+int ensure_run_scratch(gsf_ctx* ctx, size_t bytes);
 
 // wave-per-trajectory K4 / fused pipeline for the trajectory-major layout (gsf_ekf_wave.hip)
 int launch_ekf_wave(gsf_ctx* ctx, bool pipeline, const double* ts, const double* pos, const double* quat, const double* gps,
@@ -97,15 +105,28 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
                      const uint8_t* valid, const double* init_pos, const double* init_quat, const gsf_ekf_config* cfg, int64_t B,
                      int64_t N, double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status);
 
+// filter_gps_outliers_ransac as a whole, windows found on the device (gsf_gpsfilter.hip); counts (may be NULL): log b = rows offsets[b] .. +counts[b]
+int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, const int32_t* counts, int64_t B,
+                              int32_t max_log_rows, const gsf_prefilter_config* f, uint32_t* mt_state, uint8_t* keep, int32_t* log_status, int32_t* log_info);
+
+// main_process_gui's row choice as a launch of its own (gsf_robust.hip: sim3_rows_kernel; ref :973-998): row_mask[B*N] / ragged, n_rows[B], status[B]
+int launch_sim3_rows(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
+                     const FitRows& rule, uint8_t* row_mask, int32_t* n_rows, int32_t* status);
+
 // K2b launch with optional per-set row counts (sets in fixed-stride slots: rows offsets[b] .. offsets[b] + counts[b])
 int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,
                        const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
                        double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers,
-                       int64_t total_rows = 0 /* rows of src / dst if the host knows them: enables the single-precision screen */);
+                       int64_t total_rows = 0 /* rows of src / dst if the host knows them: enables the single-precision screen */,
+                       int32_t trial0 = 0 /* hypotheses below this one were scored by the early-exit probe (gsf_robust.hip) ... */,
+                       unsigned long long* keys_io = nullptr /* ... whose arg-max key per set comes in here ([B][2]) and the merged one goes out */,
+                       const int32_t* decided = nullptr /* ... and sets it decided (a trial counted every row, ref :413) are not scanned again */);
 // sample sets of the reference's RNG call, generated on the device (gsf_rng.hip): permutation(n_b)[:k] per trial from each set's
 // legacy MT19937 state; n_b = counts[b] (int32) -- asynchronous on the context's stream
 int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx,
                      int32_t n_max /* largest counts[b] if the host knows it, else 0 */);
+int launch_mt_choice_rest(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t total_trials, int32_t trial0, int32_t k,
+                          int32_t* sample_idx, int32_t n_max, const int32_t* skip);
 // the same draws for a few streams, spread over the chip (gsf_rng_tape.hip); launch_mt_choice picks it when mt_tape_applies
 bool mt_tape_applies(const gsf_ctx* ctx, int64_t B, int32_t trials, int32_t k, int32_t n_max);
 int launch_mt_tape(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t trials, int32_t k, int32_t* sample_idx, int32_t n_max,

@@ -397,7 +397,8 @@ GSF_HD bool umeyama_rotation_polar(const double* H, double* R, double& sum_sigma
 
 // status codes/flags of a Sim3 fit (mirrored in include/gsf.h)
 enum : int32_t { SIM3_OK = 0, SIM3_NONE = 1, SIM3_FLAG_VAR0 = 2, SIM3_FLAG_SMALL_SCALE = 4, SIM3_FLAG_BAD_INDEX = 8, SIM3_FLAG_SVD_FALLBACK = 16,
-                 SIM3_FLAG_FEW_ROWS = 32, SIM3_FLAG_ROWS_ALL = 64, SIM3_FLAG_ROWS_SEGMENT = 128 };   // the row choice of main_process_gui (ref :973-998)
+                 SIM3_FLAG_FEW_ROWS = 32, SIM3_FLAG_ROWS_ALL = 64, SIM3_FLAG_ROWS_SEGMENT = 128,     // the row choice of main_process_gui (ref :973-998)
+                 SIM3_FLAG_SATURATED = 256 };                                                        // robust chain, early exit: a trial counted every row (ref :413)
 
 // the SVD route of the closed form's rotation, ref :439-444: R = Vt.T @ U.T with the reflection fix, tr = S0 + S1 + S2 det(R)
 GSF_HD void umeyama_rotation_svd(const double* H, double* R, double& tr)

@@ -12,6 +12,14 @@ constexpr int MT_STATE_WORDS = 625;                       // key[624] + pos
 constexpr int CHOICE_LDS_JSEQ_MAX = 56 * 1024;            // swap partners of the trials buffered between draw and trace phases (dynamic LDS)
 constexpr int CHOICE_LDS_JSEQ_AIM = 36 * 1024;            // ... sized to this when the sets allow: four blocks per CU instead of two
 constexpr int CHOICE_MAX_N = 28000;                       // one trial's jseq (uint16 per step) must fit the buffer
+// LDS for the swap partners of up to 64 buffered trials of the LARGEST set (n_max rows; 0 = unknown): as little as the sets need, so that
+// four streams share a CU when they can
+inline int choice_lds_bytes(const int64_t n_max)
+{
+    if (n_max > 0 && n_max * 2 * 64 <= CHOICE_LDS_JSEQ_AIM) return (int)(n_max * 2 * 64);
+    if (n_max > 0 && n_max * 2 * 8 <= CHOICE_LDS_JSEQ_AIM) return CHOICE_LDS_JSEQ_AIM;
+    return CHOICE_LDS_JSEQ_MAX;
+}
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far)
 {

@@ -35,17 +35,19 @@ __global__ __launch_bounds__(64) void mt_seed_kernel(const uint32_t* __restrict_
 }
 
 // sample_idx[b][trial][0..k) = permutation(n_b)[:k] for `trials` consecutive trials of stream b; state advanced exactly as NumPy's.
+// idx_stride / trial0: stream b's sets live at sample_idx[b][idx_stride][k] and this launch fills trials trial0 .. trial0 + trials - 1 of them
+// (the continuation of the robust chain's early-exit probe, gsf_robust.hip); done_flags: streams to leave alone.
 __global__ __launch_bounds__(64) void mt_choice_kernel(uint32_t* __restrict__ state, const int32_t* __restrict__ counts, int trials, int kk,
                                                        int32_t* __restrict__ sample_idx, int jseq_bytes, const int32_t* __restrict__ done_flags,
-                                                       int done_stride)
+                                                       int done_stride, int idx_stride, int trial0)
 {
     __shared__ uint32_t mt[MT_N + 1];
     extern __shared__ uint16_t jseq[];
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
-    if (done_flags && done_flags[b * done_stride]) return;               // drawn by the chip-wide route (gsf_rng_tape.hip)
+    if (done_flags && done_flags[b * done_stride]) return;               // drawn by the chip-wide route (gsf_rng_tape.hip) / decided by the probe
     const int n = counts[b];
-    int32_t* out = sample_idx + (size_t)b * (size_t)trials * (size_t)kk;
+    int32_t* out = sample_idx + ((size_t)b * (size_t)idx_stride + (size_t)trial0) * (size_t)kk;
     if (n < kk || n < 1 || n > CHOICE_MAX_N) {                           // the reference returns before drawing (ref :395-397): stream untouched
         for (int i = lane; i < trials * kk; i += 64) out[i] = 0;
         return;
@@ -71,13 +73,21 @@ int launch_mt_choice(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64
         const int rc = launch_mt_tape(ctx, state, counts, B, trials, k, sample_idx, n_max, &done_flags, &done_stride);
         if (rc) return rc;
     }
-    // LDS for the swap partners of up to 64 buffered trials of the LARGEST set (n_max rows; 0 = unknown): as little as the sets need,
-    // so that four streams share a CU when they can
-    int bytes = CHOICE_LDS_JSEQ_MAX;
-    if (n_max > 0 && (int64_t)n_max * 2 * 64 <= CHOICE_LDS_JSEQ_AIM) bytes = n_max * 2 * 64;
-    else if (n_max > 0 && (int64_t)n_max * 2 * 8 <= CHOICE_LDS_JSEQ_AIM) bytes = CHOICE_LDS_JSEQ_AIM;
+    const int bytes = choice_lds_bytes(n_max);
     hipLaunchKernelGGL(mt_choice_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, state, counts, (int)trials, (int)k, sample_idx, bytes,
-                       done_flags, done_stride);
+                       done_flags, done_stride, (int)trials, 0);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+
+// trials trial0 .. total_trials - 1 of the streams whose skip[b] is 0, one wave per stream (the robust chain after its early-exit probe)
+int launch_mt_choice_rest(gsf_ctx* ctx, uint32_t* state, const int32_t* counts, int64_t B, int32_t total_trials, int32_t trial0, int32_t k,
+                          int32_t* sample_idx, int32_t n_max, const int32_t* skip)
+{
+    if (trial0 >= total_trials) return GSF_OK;
+    const int bytes = choice_lds_bytes(n_max);
+    hipLaunchKernelGGL(mt_choice_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, state, counts, (int)(total_trials - trial0), (int)k,
+                       sample_idx, bytes, skip, 1, (int)total_trials, (int)trial0);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

@@ -7,6 +7,8 @@
 //   K4           EKF + per-outage RTS, wave per trajectory                                              (ref :1010; gsf_ekf_wave.hip)
 //   finish       fit status into the status word, inlier mask back to original rows, NaN rows for a fit that is None
 #include "gsf_wave_common.hpp"
+#include "gsf_mt19937.hpp"
+#include "gsf_ransac.hpp"
 
 using namespace gsf;
 
@@ -110,6 +112,74 @@ __global__ __launch_bounds__(64) void compact_valid_kernel(const double* __restr
     if (lane == 0) { counts[b] = n; offsets[b] = base; if (b == B - 1) offsets[B] = B * N; }
 }
 
+
+// ---- exact early termination of the robust fit (gsf_set_option "ransac_early_exit") -------------------------------------------------
+// The reference's loop keeps a trial only if it counts STRICTLY more rows than the best so far (ref :413), so once a trial has counted all
+// n rows no later trial can change the inlier mask, the count, or the final fit: the rest of the max_trials draws only move the generator.
+// One wave per trajectory draws and scores its own trials in growing rounds (1, 1, 2, 4, ... <= 64 trials: a round costs one lane-parallel
+// 4-point fit whatever its size, a trial costs its draw -- ~2.3 us at 271 rows -- and one row-parallel count) and stops at the first trial
+// that counts every row.  A trajectory that is still undecided after `probe_trials` is handed to the wide kernels for the REST of its trials
+// (mt_choice_kernel + K2b from trial `drawn` on, the arg-max key carried over), so data that never saturates costs what it cost before.
+// Counts are formed with the functions K2b forms them with (gsf_ransac.hpp): the decision is the one the full chain takes.
+//   keys[b][2]      arg-max key of the trials scored here (0 = none usable), [1] = 0 (no caller-fed sample can be out of range)
+//   decided[b]      1 when a trial counted every row: R, t, s, mask, n_inliers are final; the generator stops after that trial's ROUND
+//   trial_info[b]   { deciding trial or -1, trials drawn here }
+__global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__ state, const double* __restrict__ src, const double* __restrict__ dst,
+                                                          const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts, int max_trials,
+                                                          int probe_trials, int ms, double thr, int32_t* sample_idx, int jseq_bytes,
+                                                          unsigned long long* __restrict__ keys, int32_t* __restrict__ decided,
+                                                          int32_t* __restrict__ trial_info)
+{
+    __shared__ uint32_t mt[MT_N + 1];
+    extern __shared__ uint16_t jseq[];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int n = counts[b];
+    const int64_t i0 = offsets[b];
+    int32_t* my_idx = sample_idx + (size_t)b * (size_t)max_trials * (size_t)ms;
+    long long best = -1; int best_trial = 0x7fffffff, drawn = 0; bool sat = false;
+    if (!(n < ms || n < 1 || n > CHOICE_MAX_N)) {                         // else: the reference returns before drawing (ref :395-397), stream untouched
+        uint32_t* st = state + b * MT_STATE_WORDS;
+        for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
+        int pos = (int)st[MT_N];
+        __syncthreads();
+        const int limit = probe_trials < max_trials ? probe_trials : max_trials;
+        for (int round = 0; drawn < limit && !sat; ++round) {
+            int T = round < 2 ? 1 : (round < 8 ? (1 << (round - 1)) : 64);
+            if (T > limit - drawn) T = limit - drawn;
+            mt_draw_choice(mt, pos, n, T, ms, jseq, jseq_bytes / 2, my_idx + (size_t)drawn * ms, nullptr, lane);   // (ends on a block barrier: the sets are visible)
+            double R[9], t[3], s = 0.0;
+            bool ok = false;
+            if (lane < T) ok = fit_sample(src, dst, i0, my_idx + (size_t)(drawn + lane) * ms, ms, R, t, s) != SIM3_NONE;   // ref :407-408
+            const u64 okm = __ballot(ok);
+            for (int h = 0; h < T; ++h) {                                  // wave-uniform: one hypothesis at a time, its rows spread over the lanes
+                if (((okm >> h) & 1ull) == 0ull) continue;
+                double Rh[9], th[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rh[k] = lane_bcast(R[k], h);
+                th[0] = lane_bcast(t[0], h); th[1] = lane_bcast(t[1], h); th[2] = lane_bcast(t[2], h);
+                const double sh = lane_bcast(s, h);
+                long long cnt = 0;
+                for (int r0 = 0; r0 < n; r0 += 64) {                       // ref :409-412
+                    const int r = r0 + lane;
+                    const bool in = r < n && is_inlier(src, dst, i0 + (r < n ? r : n - 1), Rh, th, sh, thr);
+                    cnt += __popcll(__ballot(in));
+                }
+                if (cnt > best) { best = cnt; best_trial = drawn + h; }    // strict > keeps the first (:413)
+                if (cnt == (long long)n) { sat = true; break; }            // every row counted: nothing after this trial can be kept
+            }
+            drawn += T;
+        }
+        for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
+        if (lane == 0) st[MT_N] = (uint32_t)pos;
+    }
+    if (lane == 0) {
+        keys[b * 2] = best >= 0 ? ransac_key(best, best_trial) : 0ull; keys[b * 2 + 1] = 0ull;
+        decided[b] = sat ? 1 : 0;
+        trial_info[b * 2] = sat ? best_trial : -1; trial_info[b * 2 + 1] = drawn;
+    }
+}
+
 // lane per trajectory: Sim3 of pose 0 (transform_trajectory row 0, ref :464-466)
 __global__ __launch_bounds__(64) void robust_init_pose_kernel(const double* __restrict__ pos, const double* __restrict__ quat, int64_t B, int64_t N,
                                                               const double* __restrict__ R, const double* __restrict__ t, const double* __restrict__ s,
@@ -137,11 +207,21 @@ __global__ __launch_bounds__(64) void robust_init_pose_kernel(const double* __re
 __global__ __launch_bounds__(64) void robust_finish_kernel(int64_t N, const int32_t* __restrict__ fit, const int32_t* __restrict__ fail,
                                                            const int32_t* __restrict__ rows_status, const int32_t* __restrict__ counts, const int32_t* __restrict__ rowmap,
                                                            const uint8_t* __restrict__ mask_c, uint8_t* __restrict__ inlier_mask,
-                                                           double* __restrict__ pos_out, double* __restrict__ quat_out, int32_t* __restrict__ status)
+                                                           double* __restrict__ pos_out, double* __restrict__ quat_out, int32_t* __restrict__ status,
+                                                           const int32_t* __restrict__ decided, const unsigned long long* __restrict__ keys,
+                                                           int32_t* __restrict__ trial_info, const int32_t* __restrict__ probe_info, int max_trials, int min_samples)
 {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x, base = b * N;
     const int f = fail[b];
+    const int32_t sat = (decided && decided[b]) ? SIM3_FLAG_SATURATED : 0;
+    if (trial_info && lane == 0) {
+        // { the trial whose inlier set was kept (first one with the best count, ref :413) or -1, trials drawn from the generator }
+        int win = -1, drawn = counts[b] < min_samples ? 0 : max_trials;
+        if (keys) { const unsigned long long k = keys[b * 2]; if (k) win = 0x7fffffff - (int)(k & 0xffffffffull); }
+        if (probe_info && decided && decided[b]) drawn = probe_info[b * 2 + 1];
+        trial_info[b * 2] = win; trial_info[b * 2 + 1] = drawn;
+    }
     if (inlier_mask) {
         for (int64_t i = lane; i < N; i += 64) inlier_mask[base + i] = 0;
         __syncthreads();
@@ -156,7 +236,7 @@ __global__ __launch_bounds__(64) void robust_finish_kernel(int64_t N, const int3
         const int32_t few = rows_status ? (rows_status[b] & SIM3_FLAG_FEW_ROWS) : 0;      // the reference raised ValueError before the fit (:975, :997)
         if (lane == 0) status[b] = ((f & 1) ? ((SIM3_NONE | few) << 8) : 0) | ((f & 2) ? ST_BAD_QUAT : 0);
     } else if (lane == 0) {
-        status[b] = (status[b] & 0xff) | ((fit[b] | (rows_status ? rows_status[b] : 0)) << 8);
+        status[b] = (status[b] & 0xff) | ((fit[b] | (rows_status ? rows_status[b] : 0) | sat) << 8);
     }
 }
 
@@ -164,11 +244,21 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
-                                                  const uint8_t* valid, const gsf_ekf_config* cfg, int64_t B, int64_t N, int32_t min_samples,
-                                                  double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t* mt_state,
-                                                  double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
-                                                  int32_t* n_inliers, uint8_t* inlier_mask)
+namespace gsf {
+int launch_sim3_rows(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
+                     const FitRows& rule, uint8_t* row_mask, int32_t* n_rows, int32_t* status)
+{
+    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
+}  // namespace gsf
+
+extern "C" int gsf_fuse_pipeline_robust_info_batch_dev(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
+                                                       const uint8_t* valid, const gsf_ekf_config* cfg, int64_t B, int64_t N, int32_t min_samples,
+                                                       double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t* mt_state,
+                                                       double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
+                                                       int32_t* n_inliers, uint8_t* inlier_mask, int32_t* trial_info)
 {
     GSF_REQUIRE(ctx && cfg, "ctx/cfg is NULL");
     GSF_REQUIRE(B >= 0 && N >= 0 && B <= 0x7fffffff, "bad B or N");
@@ -183,7 +273,8 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
     auto take = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes); return at; };
     const size_t o_src = take(P * 24), o_dst = take(P * 24), o_map = take(P * 4), o_mask = take(P), o_cnt = take(nb * 4), o_off = take((nb + 1) * 8),
                  o_idx = take(nb * (size_t)max_trials * (size_t)min_samples * 4 + 4), o_fit = take(nb * 4), o_fail = take(nb * 4), o_ip = take(nb * 24),
-                 o_iq = take(nb * 32), o_sel = take(P), o_rst = take(nb * 4), o_rn = take(nb * 4);
+                 o_iq = take(nb * 32), o_sel = take(P), o_rst = take(nb * 4), o_rn = take(nb * 4), o_key = take(nb * 16), o_dec = take(nb * 4),
+                 o_pinfo = take(nb * 8);
     int rc = ensure_scratch(ctx, off);
     if (rc) return rc;
     char* w = (char*)ctx->scratch;
@@ -194,21 +285,44 @@ extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts
     uint8_t* rowsel = nullptr; int32_t* rows_status = nullptr;
     if (ctx->fit_rows.mode != 0) {
         rowsel = (uint8_t*)(w + o_sel); rows_status = (int32_t*)(w + o_rst);
-        hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
-                           (int32_t*)(w + o_rn), rows_status);
-        GSF_HIP(hipGetLastError());
+        if ((rc = launch_sim3_rows(ctx, ts, gps, valid, nullptr, B, N, ctx->fit_rows, rowsel, (int32_t*)(w + o_rn), rows_status))) return rc;
     }
     hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, (const uint8_t*)rowsel, B, N, src, dst, rowmap, counts, offsets);
     GSF_HIP(hipGetLastError());
-    if (max_trials > 0 && (rc = launch_mt_choice(ctx, mt_state, counts, B, max_trials, min_samples, idx, (int32_t)N))) return rc;
+    unsigned long long* keys = (unsigned long long*)(w + o_key);         // arg-max key per trajectory: K2b leaves the winner's trial there (trial_info)
+    int32_t* decided = nullptr; int32_t* pinfo = nullptr; int32_t trial0 = 0;
+    if (!(ctx->ransac_early_exit != 0 && max_trials > 0)) GSF_HIP(hipMemsetAsync(keys, 0, nb * 16, ctx->stream));
+    if (ctx->ransac_early_exit != 0 && max_trials > 0) {
+        // growing rounds of drawn-and-scored trials per trajectory until one counts every row (ref :413), at most probe_trials of them ...
+        decided = (int32_t*)(w + o_dec); pinfo = (int32_t*)(w + o_pinfo);
+        trial0 = ctx->ransac_probe_trials < max_trials ? ctx->ransac_probe_trials : max_trials;
+        const int bytes = choice_lds_bytes(N);
+        hipLaunchKernelGGL(robust_probe_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, mt_state, (const double*)src, (const double*)dst,
+                           (const int64_t*)offsets, (const int32_t*)counts, (int)max_trials, (int)trial0, (int)min_samples, residual_threshold, idx, bytes, keys,
+                           decided, pinfo);
+        GSF_HIP(hipGetLastError());
+        // ... then the wide kernels for the rest of the trials of the trajectories that are still undecided
+        if ((rc = launch_mt_choice_rest(ctx, mt_state, counts, B, max_trials, trial0, min_samples, idx, (int32_t)N, decided))) return rc;
+    } else if (max_trials > 0 && (rc = launch_mt_choice(ctx, mt_state, counts, B, max_trials, min_samples, idx, (int32_t)N))) return rc;
     if ((rc = launch_sim3_ransac(ctx, src, dst, offsets, counts, B, idx, max_trials, min_samples, residual_threshold, min_inliers_needed, R, t, s, fit,
-                                 mask_c, n_inliers, (int64_t)P))) return rc;
+                                 mask_c, n_inliers, (int64_t)P, trial0, keys, decided))) return rc;
     hipLaunchKernelGGL(robust_init_pose_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, pos, quat, B, N, R, t, s, fit, ip, iq, fail);
     GSF_HIP(hipGetLastError());
     if ((rc = launch_ekf_wave(ctx, false, ts, pos, quat, gps, valid, ip, iq, cfg, B, N, nullptr, nullptr, nullptr, pos_out, quat_out, status))) return rc;
-    hipLaunchKernelGGL(robust_finish_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, N, fit, fail, (const int32_t*)rows_status, counts, rowmap, mask_c, inlier_mask, pos_out, quat_out, status);
+    hipLaunchKernelGGL(robust_finish_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, N, fit, fail, (const int32_t*)rows_status, counts, rowmap, mask_c, inlier_mask, pos_out, quat_out, status,
+                       (const int32_t*)decided, (const unsigned long long*)keys, trial_info, (const int32_t*)pinfo, (int)max_trials, (int)min_samples);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
+}
+
+extern "C" int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, const double* gps,
+                                                  const uint8_t* valid, const gsf_ekf_config* cfg, int64_t B, int64_t N, int32_t min_samples,
+                                                  double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t* mt_state,
+                                                  double* R, double* t, double* s, double* pos_out, double* quat_out, int32_t* status,
+                                                  int32_t* n_inliers, uint8_t* inlier_mask)
+{
+    return gsf_fuse_pipeline_robust_info_batch_dev(ctx, ts, pos, quat, gps, valid, cfg, B, N, min_samples, residual_threshold, max_trials, min_inliers_needed,
+                                                   mt_state, R, t, s, pos_out, quat_out, status, n_inliers, inlier_mask, nullptr);
 }
 
 // main_process_gui's row choice on its own (ref :973-998)
@@ -221,8 +335,5 @@ extern "C" int gsf_sim3_fit_rows_batch_dev(gsf_ctx* ctx, const double* ts, const
     if (B == 0 || (!offsets && N == 0)) return GSF_OK;
     GSF_REQUIRE(ts && valid && row_mask && n_rows, "NULL array");
     GSF_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N,
-                       FitRows{ 1, min_samples, max_gps_gap_threshold, max_initial_duration }, row_mask, n_rows, status);
-    GSF_HIP(hipGetLastError());
-    return GSF_OK;
+    return launch_sim3_rows(ctx, ts, gps, valid, offsets, B, N, FitRows{ 1, min_samples, max_gps_gap_threshold, max_initial_duration }, row_mask, n_rows, status);
 }

@@ -12,6 +12,7 @@
 // K2b: one 256-thread block per point set; one hypothesis per thread (4-point fit entirely in
 // registers), all hypotheses score the same points so the reads are wave-broadcasts out of L1/L2.
 #include "gsf_wave_common.hpp"      // DPP-routed wave_sum()
+#include "gsf_ransac.hpp"           // the hypothesis fit, residual and threshold test (shared with gsf_robust.hip)
 
 using namespace gsf;
 
@@ -419,58 +420,6 @@ __device__ __forceinline__ double block_sum(double v, double* sh, int tid)
     return r;
 }
 
-// Fit on the `ms` sampled rows, sequential sums like the reference's np.mean / matmul on 4 rows.
-__device__ __forceinline__ int32_t fit_sample(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0,
-                                              const int32_t* __restrict__ idx, int ms, double* R, double* t, double& s)
-{
-    double sc[3] = { 0, 0, 0 }, dc[3] = { 0, 0, 0 };
-    for (int k = 0; k < ms; ++k) {
-        const int64_t r = i0 + idx[k];
-        sc[0] += src[r * 3]; sc[1] += src[r * 3 + 1]; sc[2] += src[r * 3 + 2];
-        dc[0] += dst[r * 3]; dc[1] += dst[r * 3 + 1]; dc[2] += dst[r * 3 + 2];
-    }
-    const double n = (double)ms;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { sc[c] /= n; dc[c] /= n; }
-    double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ssq = 0.0;
-    for (int k = 0; k < ms; ++k) {
-        const int64_t r = i0 + idx[k];
-        const double a0 = src[r * 3] - sc[0], a1 = src[r * 3 + 1] - sc[1], a2 = src[r * 3 + 2] - sc[2];
-        const double b0 = dst[r * 3] - dc[0], b1 = dst[r * 3 + 1] - dc[1], b2 = dst[r * 3 + 2] - dc[2];
-        H[0] += a0 * b0; H[1] += a0 * b1; H[2] += a0 * b2;
-        H[3] += a1 * b0; H[4] += a1 * b1; H[5] += a1 * b2;
-        H[6] += a2 * b0; H[7] += a2 * b1; H[8] += a2 * b2;
-        ssq += a0 * a0 + a1 * a1 + a2 * a2;
-    }
-    if (ms < 3) return SIM3_NONE;
-    return umeyama_finalize(H, ssq, sc, dc, n, R, t, s);
-}
-
-// squared residual of row r under (R, t, s): pure arithmetic, so that several rows' loads can be in flight together
-__device__ __forceinline__ double resid2(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
-                                         const double* R, const double* t, double s)
-{
-    const double x = src[r * 3], y = src[r * 3 + 1], z = src[r * 3 + 2];
-    const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - dst[r * 3];
-    const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - dst[r * 3 + 1];
-    const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - dst[r * 3 + 2];
-    return dx * dx + dy * dy + dz * dz;
-}
-// ref :410-411 tests norm < thr, i.e. sqrt(d2) < thr.  The correctly rounded sqrt is only needed within a few ulp of the boundary:
-// d2 clearly below / above thr^2 decides without it (the band is ~50x wider than the rounding of d2 and thr^2).
-__device__ __forceinline__ bool within(double d2, double thr)
-{
-    const double t2 = thr * thr;
-    if (d2 < t2 * (1.0 - 1e-14)) return thr > 0.0;
-    if (!(d2 <= t2 * (1.0 + 1e-14))) return false;                          // also NaN -> false, like the comparison with sqrt(NaN)
-    return sqrt(d2) < thr;
-}
-__device__ __forceinline__ bool is_inlier(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
-                                          const double* R, const double* t, double s, double thr)
-{
-    return within(resid2(src, dst, r, R, t, s), thr);
-}
-
 // hypotheses tr = first, first + step, ... < last of set b (ref :404-414): this thread's best as a key, highest count first, then the
 // LOWEST trial (strict > keeps the first, :413); key 0 = no usable hypothesis
 __device__ __forceinline__ unsigned long long ransac_scan_trials(const double* __restrict__ src, const double* __restrict__ dst, int64_t i0, int64_t n,
@@ -500,7 +449,7 @@ __device__ __forceinline__ unsigned long long ransac_scan_trials(const double* _
         for (; r < i1; ++r) cnt += is_inlier(src, dst, r, R, t, s, thr) ? 1 : 0;
         if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
     }
-    return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+    return ransac_key(best_cnt, best_trial);
 }
 // ---- the same count with the residuals SCREENED in packed single precision.  ransac_rows_kernel writes every set's rows once as floats
 // relative to the set's first row (x' = x - x0 and y' = y - y0, differences taken in double; six component arrays in the context's
@@ -589,7 +538,7 @@ __device__ __forceinline__ unsigned long long ransac_scan_trials_screened(const 
         count_rows(nn, nall, lo_f, hi_f);                                  // far rows: their own, much wider band -- a fix 5 000 km off is an outlier for certain
         if (cnt > best_cnt) { best_cnt = cnt; best_trial = tr; }            // strict > keeps the first (:413)
     }
-    return ((unsigned long long)(best_cnt + 1) << 32) | (unsigned long long)(0x7fffffff - best_trial);
+    return ransac_key(best_cnt, best_trial);
 }
 // rows of every set as floats relative to the set's first row, NEAR rows first: frows = six arrays of `total` floats (x', y', z' of src,
 // then of dst), ridx = the row each slot came from (offset inside the set), fhdr[b] = { x0[3], y0[3], L_src, L_dst, n_near } (16 doubles
@@ -600,7 +549,7 @@ constexpr double RANSAC_NEAR_M = 65536.0;
 constexpr int RANSAC_HDR = 16;
 __global__ __launch_bounds__(256) void ransac_rows_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
                                                           const int32_t* __restrict__ counts, int64_t total, float* __restrict__ frows,
-                                                          int32_t* __restrict__ ridx, double* __restrict__ fhdr)
+                                                          int32_t* __restrict__ ridx, double* __restrict__ fhdr, const int32_t* __restrict__ decided)
 {
     __shared__ double sh_max[16];
     __shared__ int sh_cnt[4];
@@ -608,7 +557,8 @@ __global__ __launch_bounds__(256) void ransac_rows_kernel(const double* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b = blockIdx.x;
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
-    if (n <= 0 || i0 < 0 || i0 + n > total) { if (tid == 0) fhdr[b * RANSAC_HDR + 6] = NAN; return; }   // NaN extent: the set is counted in double
+    // (a set the early-exit probe decided is not scanned again: nothing to stage)
+    if (n <= 0 || i0 < 0 || i0 + n > total || (decided && decided[b])) { if (tid == 0) fhdr[b * RANSAC_HDR + 6] = NAN; return; }   // NaN extent: the set is counted in double
     // reference point: the component-wise median of five probe rows (first, quartiles, last) -- one or two wild rows among them (a set
     // that STARTS with a missing fix is ordinary) do not drag it away from the track.  It need not be a row; NaN sorts last.
     double x0[3], y0[3];
@@ -800,7 +750,8 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, double* __restrict__ Rout,
     double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status, uint8_t* __restrict__ inlier_mask,
-    int32_t* __restrict__ n_inliers, const float* __restrict__ frows, const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total)
+    int32_t* __restrict__ n_inliers, const float* __restrict__ frows, const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total,
+    int trial0, unsigned long long* __restrict__ keys_io, const int32_t* __restrict__ decided)
 {
     __shared__ unsigned long long sh_key[RANSAC_THREADS / 64];
     __shared__ double sh_fit[13];
@@ -816,12 +767,15 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     }
     const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
     bool bad_index = false;
-    unsigned long long key;
+    unsigned long long key = 0ull;
     RansacRows rows;
-    if (ransac_rows_of_set(frows, ridx, fhdr, total, b, i0, rows)) {         // block-uniform
-        key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+    // hypotheses trial0 .. trials - 1 (trial0 > 0: the ones before were scored by the early-exit probe of the robust chain, whose best comes
+    // in through keys_io; a set it DECIDED -- some trial counted every row, so no later one can replace it, ref :413 -- is not scanned)
+    if (decided && decided[b]) {                                             // block-uniform
+    } else if (ransac_rows_of_set(frows, ridx, fhdr, total, b, i0, rows)) {  // block-uniform
+        key = wave_max_key(ransac_scan_trials_screened(src, dst, i0, n, rows, my_idx, trial0 + tid, trials, RANSAC_THREADS, ms, thr, bad_index));
     } else {
-        key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, tid, trials, RANSAC_THREADS, ms, thr, bad_index));
+        key = wave_max_key(ransac_scan_trials(src, dst, i0, n, my_idx, trial0 + tid, trials, RANSAC_THREADS, ms, thr, bad_index));
     }
     const bool any_bad = __syncthreads_or(bad_index ? 1 : 0) != 0;
     if ((tid & 63) == 0) sh_key[tid >> 6] = key;
@@ -829,6 +783,11 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     key = sh_key[0];
 #pragma unroll
     for (int w = 1; w < RANSAC_THREADS / 64; ++w) key = sh_key[w] > key ? sh_key[w] : key;
+    if (keys_io) {                                                           // the same ordering across both parts: count first, then the lowest trial
+        const unsigned long long before = keys_io[b * 2];
+        key = before > key ? before : key;
+        if (tid == 0) keys_io[b * 2] = key;
+    }
     ransac_finish(b, key, any_bad, src, dst, i0, n, my_idx, ms, thr, min_inliers, Rout, tout, sout, status, inlier_mask, n_inliers, sh_fit, sh_red);
 }
 
@@ -838,12 +797,13 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
 __global__ __launch_bounds__(64) void ransac_scan_kernel(const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets,
                                                          const int32_t* __restrict__ counts, const int32_t* __restrict__ sample_idx, int trials, int ms,
                                                          double thr, unsigned long long* __restrict__ keys, const float* __restrict__ frows,
-                                                         const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total)
+                                                         const int32_t* __restrict__ ridx, const double* __restrict__ fhdr, int64_t total, int trial0,
+                                                         const int32_t* __restrict__ decided)
 {
     const int64_t b = blockIdx.y;
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b];
-    if (n < ms) return;
-    const int tr = blockIdx.x * 64 + threadIdx.x;
+    if (n < ms || (decided && decided[b])) return;
+    const int tr = trial0 + blockIdx.x * 64 + threadIdx.x;
     bool bad_index = false;
     const int32_t* my_idx = sample_idx + (size_t)b * (size_t)trials * (size_t)ms;
     unsigned long long key;
@@ -991,34 +951,36 @@ __global__ __launch_bounds__(256) void apply_sim3_slab_kernel(const double* __re
 namespace gsf {
 int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const int64_t* offsets, const int32_t* counts, int64_t B,
                        const int32_t* sample_idx, int32_t trials, int32_t min_samples, double thr, int32_t min_inliers, double* R, double* t,
-                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers, int64_t total_rows)
+                       double* s, int32_t* status, uint8_t* inlier_mask, int32_t* n_inliers, int64_t total_rows, int32_t trial0,
+                       unsigned long long* keys_io, const int32_t* decided)
 {
     // residual counts screened in packed single precision with an exact double re-check inside the error band (the counts are the
     // double kernel's); needs the rows as floats in the workspace, hence their total number (0 = unknown to the host: double
     // throughout, as with gsf_set_option "k2b_screen" 0)
     const float* frows = nullptr; const double* fhdr = nullptr; const int32_t* ridx = nullptr;
-    if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows < ((int64_t)1 << 31) && trials >= 64) {   // (slots and row indices of the screen are int32)
+    if (ctx->k2b_screen != 0 && total_rows > 0 && total_rows < ((int64_t)1 << 31) && trials - trial0 >= 64) {   // (slots and row indices of the screen are int32)
         const size_t hdr_bytes = ((size_t)B * RANSAC_HDR * 8 + 255) & ~(size_t)255;
         const int rc = ensure_k2b_scratch(ctx, hdr_bytes + (size_t)total_rows * 28);
         if (rc) return rc;
         double* h = (double*)ctx->k2b_scratch; float* f = (float*)((char*)ctx->k2b_scratch + hdr_bytes); int32_t* ri = (int32_t*)(f + (size_t)total_rows * 6);
-        hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, ri, h);
+        hipLaunchKernelGGL(ransac_rows_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, src, dst, offsets, counts, total_rows, f, ri, h, decided);
         GSF_HIP(hipGetLastError());                                       // a failed staging launch must not leave the scoring kernels on unstaged rows
         frows = f; fhdr = h; ridx = ri;
     }
-    if (B <= RANSAC_SPLIT_MAX_SETS && trials >= 256) {
+    if (B <= RANSAC_SPLIT_MAX_SETS && trials - trial0 >= 256) {
         // few sets: hypotheses spread over the chip, then one finishing block per set
-        unsigned long long* keys = (unsigned long long*)ctx->small_scratch;
-        GSF_HIP(hipMemsetAsync(keys, 0, (size_t)B * 16, ctx->stream));
-        hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
-                           sample_idx, (int)trials, (int)min_samples, thr, keys, frows, ridx, fhdr, total_rows);
+        unsigned long long* keys = keys_io ? keys_io : (unsigned long long*)ctx->small_scratch;
+        if (!keys_io) GSF_HIP(hipMemsetAsync(keys, 0, (size_t)B * 16, ctx->stream));
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials - trial0 + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
+                           sample_idx, (int)trials, (int)min_samples, thr, keys, frows, ridx, fhdr, total_rows, (int)trial0, decided);
         hipLaunchKernelGGL(ransac_finish_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
                            (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
     }
     hipLaunchKernelGGL(ransac_batch_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
-                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers, frows, ridx, fhdr, total_rows);
+                       (int)trials, (int)min_samples, thr, (int)min_inliers, R, t, s, status, inlier_mask, n_inliers, frows, ridx, fhdr, total_rows,
+                       (int)trial0, keys_io, decided);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }

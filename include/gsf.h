@@ -64,6 +64,44 @@ typedef struct {
     int32_t reserved;
 } gsf_ekf_config;
 
+/* CONFIG['gps_filtering_ransac'] / CONFIG['ground_truth_gps_filtering'] of the reference (EKFGPSSLAM.py:39-48, :55-64) */
+typedef struct {
+    int32_t enabled;                   /* :40  0: the log passes unfiltered and nothing is drawn (:139-141) */
+    int32_t use_sliding_window;        /* :41  0: one fit over the whole log (:148-182) */
+    double window_duration_seconds;    /* :42 */
+    double window_step_factor;         /* :43 */
+    int32_t polynomial_degree;         /* :44 */
+    int32_t min_samples;               /* :45 */
+    double residual_threshold_meters;  /* :46 */
+    int32_t max_trials;                /* :47 */
+    int32_t max_windows;               /* not a reference value: cap on the windows the device loop visits per log (0 = 4096) */
+    double stop_probability;           /* scikit-learn's RANSACRegressor default 0.99 (0 = that) */
+} gsf_prefilter_config;
+
+/* everything main_process_gui reads from CONFIG between its step 1 and its step 6 (EKFGPSSLAM.py:22-71) */
+typedef struct {
+    gsf_ekf_config ekf;                /* :24-29, :67-70 */
+    gsf_prefilter_config gps_filter;   /* :39-48 */
+    double sim3_residual_threshold;    /* :34 */
+    double sim3_max_initial_duration;  /* :37 */
+    double max_gps_gap_threshold;      /* :53 */
+    double eval_skip_seconds;          /* 5.0, literal in :1018 */
+    int32_t sim3_min_samples;          /* :33 */
+    int32_t sim3_max_trials;           /* :35 */
+    int32_t sim3_min_inliers_needed;   /* :36 */
+    int32_t reserved;
+} gsf_run_config;
+
+/* per-trajectory outcome of gsf_run_fusion_batch_dev: where the reference's run would have stopped */
+#define GSF_RUN_OK 0
+#define GSF_RUN_GPS_EMPTY 1            /* no GNSS row passes the lat/lon range mask: load_gps_data raises ValueError (EKFGPSSLAM.py:264) */
+#define GSF_RUN_GPS_FEW 2              /* fewer than 2 fixes left after the pre-filter: ValueError (:283, :967) */
+#define GSF_RUN_PREFILTER_UNHANDLED 4  /* the device pre-filter does not cover this log (unsorted stamps, scikit-learn's sampler outside its
+                                          permutation range 0.01 < min_samples / n < 0.99, more than max_windows windows): NaN outputs; the
+                                          caller runs that track through the host route from its saved generator state */
+#define GSF_RUN_SIM3_FAILED 8          /* ValueError of the row choice (:975, :997) or RuntimeError of the failed fit (:1003): see status >> 8 */
+#define GSF_RUN_BAD_QUAT 16            /* a SLAM quaternion of the track cannot be normalised: SciPy raises in transform_trajectory (:466) */
+
 /* status of a Sim3 fit: GSF_SIM3_NONE <=> the reference returned (None, None, None) */
 #define GSF_SIM3_OK 0
 #define GSF_SIM3_NONE 1
@@ -78,6 +116,11 @@ typedef struct {
                                          comes with GSF_SIM3_NONE, NaN outputs, and (robust chain) an untouched generator */
 #define GSF_SIM3_FLAG_ROWS_ALL 64     /* informational: the first gap-free segment is shorter than min_samples -> all valid rows (:984-986) */
 #define GSF_SIM3_FLAG_ROWS_SEGMENT 128 /* informational: fewer than min_samples rows inside max_initial_duration -> the whole first segment (:993-995) */
+/* robust chain with gsf_set_option "ransac_early_exit" 1 (compute_sim3_transform_robust, EKFGPSSLAM.py:404-414) */
+#define GSF_SIM3_FLAG_SATURATED 256   /* informational: a trial counted EVERY row of the fit, so by the strict '>' of :413 no later trial could
+                                         have replaced it and the trajectory stopped drawing there: R, t, s, inlier mask, n_inliers and
+                                         the fused poses are the all-max_trials result bit for bit; only its generator was advanced by
+                                         fewer trials (trial_info of gsf_fuse_pipeline_robust_info_batch_dev says how many) */
 
 /* status bits of a fused trajectory */
 #define GSF_ST_HAD_OUTAGE 1
@@ -107,25 +150,40 @@ GSF_API int gsf_synchronize(gsf_ctx *ctx);
    (the size of the largest call, up to 32 MB pinned), the float rows of the K2b screen (28 B per row + 25 %) and -- chosen
    automatically for <= 16 MT19937 streams of <= 2 040 rows -- the tape and transition tables of the chip-wide draws (up to 768 MB,
    960 MB with the growth margin; a few MB at the reference's own shape of one stream of 271 rows).  gsf_trim synchronises the stream
-   and releases all of them (they grow again on demand); call it before sizing a large allocation to what the device has free. */
+   and releases all of them (they grow again on demand); call it before sizing a large allocation to what the device has free.
+   A hipGraph captured from calls on this context holds workspace addresses as kernel arguments: after gsf_trim -- and after any call
+   that made a workspace grow -- such a graph must be captured again before it is replayed. */
 GSF_API int gsf_trim(gsf_ctx *ctx);
 /* tuning knobs; keys:
      "duo_kernel"     -1 automatic (default) / 0 never / 1 always: two-wave build of the fused pipeline for small batches of short tracks
      "lane_min_traj"  time-major batches with fewer trajectories than this (default 32768) are transposed and run by the
                       wave-per-trajectory kernel; 0 = always the lane-per-trajectory kernel
      "block_kernel"   -1 / 0 never (what -1 means today) / 1 whenever it applies: workgroup-per-trajectory EKF kernel for 64 < N <= 1024
+                      (under gsf_set_sim3_rows mode 1 its launcher marks the rows of the fit with a launch of their own first)
      "tape_draws"     -1 automatic (default): up to 16 MT19937 streams of <= 2040 rows are drawn chip-wide (csrc/gsf_rng_tape.hip) /
                       0 always one wave per stream / 2 tests only (a tape cut short: the one-wave kernel must take over)
      "k2b_screen"     1 (default): the residual counts of the RANSAC hypotheses are screened in packed single precision and re-checked in
                       double inside the rounding band (identical counts) / 0: double throughout.  The band carries 1e-6 m of slack for
                       the double path's own rounding, which covers coordinates up to ~1e9 m in magnitude (UTM: 1e7); rows beyond
                       that should be fitted with the screen off
+     "ransac_early_exit"  0 (default): every trajectory of the robust chain draws and scores all max_trials hypotheses, so its generator
+                      ends where np.random ends after compute_sim3_transform_robust (EKFGPSSLAM.py:404-405) / 1: a trajectory stops at
+                      the first trial that counts every row of its fit -- :413 keeps a trial only on a STRICTLY larger count, so no later
+                      trial can change the mask, the count or the final fit; outputs identical bit for bit, GSF_SIM3_FLAG_SATURATED in the
+                      status word, the generator left after the round of trials that held the deciding one (rounds of 1, 1, 2, 4, ...
+                      <= 64 trials).  Trajectories that never saturate (one GNSS outlier beyond the threshold is enough) run all
+                      max_trials as before.  The Python batch binding switches it ON, the single-track drop-in never uses it
+     "ransac_probe_trials"  (default 64) how many trials the early-exit probe draws and scores per trajectory (one wave each) before
+                      the wide kernels take the rest of an undecided trajectory's trials
      "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift
      "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);
-/* Which rows feed the Sim3 fit of the fused chains (gsf_fuse_pipeline_*, gsf_fuse_pipeline_robust_*) on this context from now on.
-     mode 0 (default)  every row with valid, finite GNSS (the operator SURVEY 8(b)/(d) defined for the batch configs)
-     mode 1            what main_process_gui does between its alignment and its fit (EKFGPSSLAM.py:973-998): of the valid rows V (in row
+/* Which rows feed the Sim3 fit of the fused chains (gsf_fuse_pipeline_*, gsf_fuse_pipeline_robust_*, gsf_run_fusion_batch_*) on this context
+   from now on.  A context STARTS in mode 1 with the reference's CONFIG defaults (min_samples 4, max_gps_gap_threshold 5.0 s,
+   max_initial_duration 180.0 s; EKFGPSSLAM.py:34, :53, :37), so a caller that sets nothing gets steps 3-5 as main_process_gui runs them;
+   the Python binding (batch.py, fit_rows="reference") sets the same mode from its CONFIG dict on every call.
+     mode 0            every row with valid, finite GNSS (the operator SURVEY 8(b)/(d) defined for the batch configs)
+     mode 1 (default)  what main_process_gui does between its alignment and its fit (EKFGPSSLAM.py:973-998): of the valid rows V (in row
                        order), the rows before the first k with ts[V[k+1]] - ts[V[k]] > max_gps_gap_threshold -- V[k] itself is left out,
                        :981-982 -- or all of V when there is no such k; if those are fewer than min_samples: all of V (:984-986); else
                        the rows of that segment with ts <= ts[V[0]] + max_initial_duration, or the whole segment when fewer than
@@ -219,6 +277,15 @@ GSF_API int gsf_gps_prefilter_chain(gsf_ctx *ctx, const double *t, const double 
                                     const int32_t *win_rows, const int64_t *win_offsets, int32_t max_window_rows, int32_t max_trials,
                                     int32_t min_samples, int32_t degree, double residual_threshold, double stop_probability,
                                     uint32_t *mt_state, uint8_t *keep, int32_t *win_status, int32_t *log_status);
+/* filter_gps_outliers_ransac AS A WHOLE for B logs (EKFGPSSLAM.py:136-247), no host step: the windows are found on the device from the
+   stamps the way the reference walks them (:199-234: [w0, w0 + duration) advanced by duration x step_factor, one extra tail window, windows
+   with fewer than min_samples rows skipped), or one global window (:148-182; a failing fit passes the log unfiltered), plus the
+   reference's early-outs (disabled, fewer rows than min_samples: everything kept, nothing drawn).  Sorted stamps only (log_status 3
+   otherwise); max_log_rows >= the longest log.  log_info[B][2] (may be NULL) = { windows fitted, windows that found a consensus }.
+   Draws, acceptance walk, generator handling: as gsf_gps_prefilter_chain_dev. */
+GSF_API int gsf_gps_prefilter_auto_dev(gsf_ctx *ctx, const double *t, const double *pos, const int64_t *offsets, int64_t B, int32_t max_log_rows,
+                                       const gsf_prefilter_config *filter, uint32_t *mt_state, uint8_t *keep, int32_t *log_status,
+                                       int32_t *log_info);
 
 /* ---- K2: Sim3 / Umeyama (compute_sim3_transform, EKFGPSSLAM.py:428-459) ------------------- */
 /* B ragged point sets: src/dst are [total][3]; offsets int64[B+1].  Optional `mask` (uint8[total], may be NULL)
@@ -329,12 +396,43 @@ GSF_API int gsf_fuse_pipeline_robust_batch_dev(gsf_ctx *ctx, const double *ts, c
                                                double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t *mt_state,
                                                double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status,
                                                int32_t *n_inliers, uint8_t *inlier_mask);
+/* the same with trial_info[B][2] (int32, may be NULL): { the trial whose inlier set was kept -- the first one with the best count, :413 --
+   or -1 when no trial was usable, the number of trials drawn from the trajectory's generator } (max_trials unless
+   gsf_set_option "ransac_early_exit" stopped it early; 0 where the reference returns before drawing, :395-397) */
+GSF_API int gsf_fuse_pipeline_robust_info_batch_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
+                                                    const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N, int32_t min_samples,
+                                                    double residual_threshold, int32_t max_trials, int32_t min_inliers_needed,
+                                                    uint32_t *mt_state, double *R, double *t, double *s, double *pos_out, double *quat_out,
+                                                    int32_t *status, int32_t *n_inliers, uint8_t *inlier_mask, int32_t *trial_info);
 /* host arrays; mt_state[B][625] in/out as in gsf_sim3_ransac_mt_batch (np.random.get_state(): key[624] + pos) */
 GSF_API int gsf_fuse_pipeline_robust_batch(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,
                                            const uint8_t *valid, const gsf_ekf_config *cfg, int64_t B, int64_t N, int32_t min_samples,
                                            double residual_threshold, int32_t max_trials, int32_t min_inliers_needed, uint32_t *mt_state,
                                            double *R, double *t, double *s, double *pos_out, double *quat_out, int32_t *status,
                                            int32_t *n_inliers, uint8_t *inlier_mask);
+
+/* ---- steps 1-6 of main_process_gui for B trajectories as ONE device chain (EKFGPSSLAM.py:959-1033) -------------------------------
+   In: B SLAM tracks of N poses (ts[B][N], pos[B][N][3], quat[B][N][4]: what load_slam_trajectory returns, :959) and their GNSS logs as
+   load_gps_data reads them (:258): fixes gps_offsets[b]..gps_offsets[b+1] of gps_t[total] and gps_llh[total][3] = (col 1, col 2, col 3 of
+   the text file: read as lat deg, lon deg, alt m).  total_fixes = gps_offsets[B], max_fixes >= the longest log (both known to the HOST:
+   they size the workspace).  mt_state[B][625] in/out: each trajectory's NumPy legacy generator (np.random.get_state(): key[624] + pos);
+   the pre-filter of step 1 and the robust fit of step 3 draw from it in the reference's order.
+   Chain: lat/lon range mask, zone pick, UTM forward (:259-271) -> sliding-window RANSAC pre-filter (:275, :136-247) -> dynamic_time_alignment
+   to the SLAM stamps (:971) -> the rows of the global fit (:973-998; this entry always applies the reference's choice with cfg's values,
+   whatever gsf_set_sim3_rows says) -> compute_sim3_transform_robust (:1002; gsf_set_option "ransac_early_exit" applies) ->
+   transform_trajectory (:1006) -> apply_ekf_correction (:1010) -> the error metric of step 6 against the primary GPS (:1013-1033).
+   Out: R[B][9], t[B][3], s[B], pos_out[B][N][3], quat_out[B][N][4], status[B] (GSF_ST_* | GSF_SIM3_* << 8), n_inliers[B];
+   zone[B] / south[B]; gps_utm[total][3] = (E, N, alt), NaN rows where the loader drops the fix; gps_keep[total] = 1 on the fixes that
+   survive loader and pre-filter (what load_gps_data returns); aligned[B][N][3] / valid[B][N] = step 2's output; sim3_pos[B][N][3] (may be
+   NULL) = step 4's positions; err_stats[3][B][4] = { count, mean, median, RMSE } of raw SLAM / Sim3 / EKF (:1027-1033);
+   run_status[B] = GSF_RUN_* (a trajectory on which the reference raises has NaN outputs and its generator where the reference left it);
+   inlier_mask[B][N] and trial_info[B][2] as in gsf_fuse_pipeline_robust_info_batch_dev (may be NULL). */
+GSF_API int gsf_run_fusion_batch_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, int64_t B, int64_t N,
+                                     const double *gps_t, const double *gps_llh, const int64_t *gps_offsets, int64_t total_fixes,
+                                     int32_t max_fixes, const gsf_run_config *cfg, uint32_t *mt_state, double *R, double *t, double *s,
+                                     double *pos_out, double *quat_out, int32_t *status, int32_t *n_inliers, int32_t *zone, int32_t *south,
+                                     double *gps_utm, uint8_t *gps_keep, double *aligned, uint8_t *valid, double *sim3_pos,
+                                     double *err_stats, int32_t *run_status, uint8_t *inlier_mask, int32_t *trial_info);
 
 /* ragged forms (trajectories of different lengths): flat [total][C] arrays, trajectory b = rows offsets[b]..offsets[b+1] */
 GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,

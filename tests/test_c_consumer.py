@@ -52,6 +52,8 @@ def test_consumer_fails_loudly_without_a_device(exe, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows", ["reference", "all"])
 def test_c_consumer_equals_the_python_route(exe, tmp_path, rows):
+    """rows="reference": the C process sets NOTHING on its fresh context -- the library's default row rule must be the reference's flow
+    (main_process_gui, EKFGPSSLAM.py:973-998) and equal the Python route's fit_rows="reference" bit for bit; "all": it switches to mode 0."""
     import torch
     from gps_optimize_slam_amd import batch as B
     nb, N = 96, 271

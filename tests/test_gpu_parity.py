@@ -1474,12 +1474,15 @@ def test_chip_wide_draws_match_numpy(B):
         B.context().set_option("tape_draws", -1)
 
 
+@pytest.mark.parametrize("early_exit", [False, True])
 @pytest.mark.parametrize("fit_rows", ["reference", "all"])
 @pytest.mark.parametrize("nb", [24, 8])
-def test_robust_pipeline_chain_vs_oracle(B, orc, nb, fit_rows):
+def test_robust_pipeline_chain_vs_oracle(B, orc, nb, fit_rows, early_exit):
     """RANSAC -> final fit -> Sim3 of pose 0 -> EKF+RTS as ONE device chain with the draws generated on the device, against the
     oracle fed with NumPy's own draws for the same seeds: identical inlier masks / counts, R, t, s and fused poses inside the gate.
-    24 streams are drawn one wave per stream, 8 by the chip-wide route (csrc/gsf_rng_tape.hip), the empty set among them by neither."""
+    24 streams are drawn one wave per stream, 8 by the chip-wide route (csrc/gsf_rng_tape.hip), the empty set among them by neither.
+    early_exit: the planted outliers keep every trajectory from saturating, so the probe must hand ALL of them to the wide kernels and
+    every generator still ends where NumPy's ends (trial_info: max_trials drawn, no GSF_SIM3_FLAG_SATURATED)."""
     N = 271
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=41)
     h = batch.host_traj_major()
@@ -1494,9 +1497,10 @@ def test_robust_pipeline_chain_vs_oracle(B, orc, nb, fit_rows):
     cfg = B.CONFIG["sim3_ransac"]
     seeds = np.arange(100, 100 + nb)
     st = B.mt19937_seed(seeds)
-    out, R, t, s, nin, mask = B.fuse_pipeline_robust_batch(batch, st, fit_rows=fit_rows)
+    out, R, t, s, nin, mask, info = B.fuse_pipeline_robust_batch(batch, st, fit_rows=fit_rows, early_exit=early_exit, return_info=True)
     p, q, status = out.host_traj_major()
-    R, t, s, nin, mask = R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy(), nin.cpu().numpy(), mask.cpu().numpy()
+    R, t, s, nin, mask, info = R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy(), nin.cpu().numpy(), mask.cpu().numpy(), info.cpu().numpy()
+    assert not ((status >> 8) & 256).any()                                # nobody saturates: every track holds fixes 40 m off
     plain = B.fuse_pipeline_batch(batch, fit_rows=fit_rows)[1].cpu().numpy()
     differs = 0
     for b in range(nb):
@@ -1517,6 +1521,7 @@ def test_robust_pipeline_chain_vs_oracle(B, orc, nb, fit_rows):
         key, pos = np.random.get_state()[1:3]
         got = st[b].cpu().numpy().view(np.uint32)
         np.testing.assert_array_equal(got[:624], key); assert int(got[624]) == int(pos)
+        assert info[b, 1] == (cfg["max_trials"] if ok.sum() >= cfg["min_samples"] else 0)
         if res[0] is None:
             assert (status[b] >> 8) & 1 and np.isnan(p[b]).all() and np.isnan(R[b]).all()
             continue
@@ -1595,7 +1600,7 @@ def test_host_pointer_forms_equal_device_forms(B):
     r = CONFIG["sim3_ransac"]
     st_dev = B.mt19937_seed(np.arange(100, 100 + nb))
     st_host = st_dev.cpu().numpy().copy()
-    outr, Rr, tr, sr, nin, mask = B.fuse_pipeline_robust_batch(batch, st_dev)
+    outr, Rr, tr, sr, nin, mask = B.fuse_pipeline_robust_batch(batch, st_dev, early_exit=False)      # (the option lives on the context: the host-pointer call below runs the same mode)
     pr, qr, str_ = outr.host_traj_major()
     ninh, maskh = np.empty(nb, dtype=np.int32), np.empty((nb, N), dtype=np.uint8)
     _lib.check(L.gsf_fuse_pipeline_robust_batch(h, hp(hb["ts"]), hp(hb["pos"]), hp(hb["quat"]), hp(hb["gps"]), hp(hb["valid"]), C.byref(cfg), nb, N,
@@ -1662,6 +1667,57 @@ def test_host_pointer_forms_equal_device_forms(B):
         np.testing.assert_array_equal(a, b_.cpu().numpy())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,N,probe", [(1000, 271, 64), (1000, 271, 3), (2500, 150, 64), (300, 1000, 16), (9, 271, 64), (9, 271, 2)])
+def test_robust_early_exit_equals_the_full_chain_bit_for_bit(B, nb, N, probe):
+    """gsf_set_option "ransac_early_exit": a trajectory stops at the first trial that counts every row of its fit (ref :413: only a STRICTLY
+    larger count replaces the kept trial).  Against the chain that draws all max_trials, on the bench batch (1 000 x 271) and other
+    shapes, with every 7th track given one fix 30 m off (it can never saturate: the wide kernels take its trials from where the probe
+    stopped, carrying the arg-max key over) and every 11th a fix 3.9 m off (saturates late or never): R, t, s, n_inliers, inlier masks,
+    fused poses, status words (but for the SATURATED bit) and the kept trial identical in every word; probe = 2 / 3 / 16 moves the
+    hand-over point so that tracks saturating later are decided by the wide kernels with the probe's key merged in; 9 tracks: the
+    few-sets form of K2b (hypotheses spread over the chip, keys merged by atomicMax)."""
+    import torch
+    bt = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=20250523)
+    g = torch.Generator(device="cpu"); g.manual_seed(nb + N)
+    rowmask = B.sim3_fit_rows_batch(bt.ts, bt.gps, bt.valid)[0].cpu()      # (the planted fixes sit among the rows the fit sees; they stay finite, so the choice of rows does not move)
+    hit = torch.zeros(nb, dtype=torch.bool, device="cuda")
+    for b in range(0, nb, 7):
+        rows = torch.nonzero(rowmask[b] != 0).ravel()
+        if rows.numel() > 8:
+            bt.gps[b, int(rows[int(torch.randint(0, rows.numel(), (1,), generator=g))])] += 30.0; hit[b] = True
+    for b in range(3, nb, 11):
+        rows = torch.nonzero(rowmask[b] != 0).ravel()
+        if rows.numel() > 8: bt.gps[b, int(rows[int(torch.randint(0, rows.numel(), (1,), generator=g))]), 0] += 3.9
+    seeds = torch.arange(nb, dtype=torch.int64) + 1000
+    ctx = B.context()
+    st_f = B.mt19937_seed(seeds)
+    full = B.fuse_pipeline_robust_batch(bt, st_f, early_exit=False, return_info=True)
+    ctx.set_option("ransac_probe_trials", probe)
+    try:
+        st_e = B.mt19937_seed(seeds)
+        ee = B.fuse_pipeline_robust_batch(bt, st_e, early_exit=True, return_info=True)
+    finally:
+        ctx.set_option("ransac_probe_trials", 64)
+    SAT = 256 << 8
+    (o, R, t, s, nin, mask, info), (oe, Re, te, se, nine, maske, infoe) = full, ee
+    for a, b_ in ((o.pos, oe.pos), (o.quat, oe.quat), (R, Re), (t, te), (s, se)):
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0).view(torch.int64), torch.nan_to_num(b_, nan=-1.0).view(torch.int64))
+    assert torch.equal(nin, nine) and torch.equal(mask, maske) and torch.equal(o.status, oe.status & ~SAT)
+    assert torch.equal(info[:, 0], infoe[:, 0])                             # the same trial's inlier set was kept
+    sat = (oe.status & SAT) != 0
+    trials = B.CONFIG["sim3_ransac"]["max_trials"]
+    assert not (o.status & SAT).any() and (info[:, 1][nin >= 0] == trials).all()
+    # a saturated track drew only the probe's rounds, an unsaturated one everything -- and then its generator ends where the full chain's ends
+    assert (infoe[sat, 1] <= min(probe, trials)).all() and (infoe[~sat, 1] == info[~sat, 1]).all()
+    assert torch.equal(st_f[~sat], st_e[~sat])
+    fitrows = B.sim3_fit_rows_batch(bt.ts, bt.gps, bt.valid)[1]
+    assert torch.equal(sat, (nin == fitrows) & (info[:, 0] >= 0) & (info[:, 0] < probe))
+    assert not sat[hit].any() and (nb < 100 or (sat.sum() > nb // 2))           # the 30 m fixes keep their tracks going; most clean tracks stop early
+    print(f"[early exit {nb} x {N}, probe {probe}] saturated {int(sat.sum())}/{nb}; trials drawn by saturated tracks: "
+          f"{torch.bincount(infoe[sat, 1].long()).nonzero().ravel().tolist()} -> {torch.bincount(infoe[sat, 1].long())[torch.bincount(infoe[sat, 1].long()) > 0].tolist()}")
+
+
 @contextlib.contextmanager
 def block_kernel(B):
     """the workgroup-per-trajectory kernel behind the trajectory-major entry points (gsf_set_option "block_kernel" 1), restored afterwards"""
@@ -1673,25 +1729,31 @@ def block_kernel(B):
         ctx.set_option("block_kernel", -1)
 
 
+@pytest.mark.parametrize("rows", ["reference", "all"])
 @pytest.mark.parametrize("N", [65, 129, 300, 640, 777, 1024])
-def test_block_kernel_outage_stress_vs_oracle(B, orc, N):
+def test_block_kernel_outage_stress_vs_oracle(B, orc, N, rows):
     """gsf_ekf_block.hip (one wave per 64-pose chunk, two-level scans through LDS) on the outage-stress tracks: up to four outages of 1..N/2
     poses (i.e. crossing up to eight chunk boundaries: the first-recovery records of barrier 4), NaN fixes, sharp-turn recoveries,
-    outages at both ends, non-unit quaternions -- K4 against the dense oracle, status bits exact; the fused pipeline against the oracle's."""
+    outages at both ends, non-unit quaternions -- K4 against the dense oracle, status bits exact; the fused pipeline against the oracle's,
+    under both row rules (the reference's choice ref :973-998 reaches this kernel as a row mask from a launch of sim3_rows_kernel: row bits
+    of the status word exact, and a forced block_kernel = 1 must really run this kernel -- round 4 rerouted it silently)."""
     nb = 160
     ts, pos, quat, gps, valid, ip, iq = _random_outage_batch(nb, N, seed=500 + N)
     po, qo, sto = orc.fuse_batch(ts, pos, quat, gps, valid, ip, iq)
-    pr, qr, str_, Rr, tr, sr = orc.fuse_pipeline_batch(ts, pos, quat, gps, valid)
+    pr, qr, str_, Rr, tr, sr = orc.fuse_pipeline_batch(ts, pos, quat, gps, valid, fit_rows=rows)
     with block_kernel(B):
         batch = B.TrajectoryBatch.from_host(ts, pos, quat, gps, valid, ip, iq, layout=0)
         p, q, st = B.ekf_fuse_batch(batch).host_traj_major()
-        out, R, t, s = B.fuse_pipeline_batch(batch)
+        out, R, t, s = B.fuse_pipeline_batch(batch, fit_rows=rows)
         pp, qp, stp = out.host_traj_major()
     np.testing.assert_array_equal(st, sto)
     assert np.abs(p - po).max() < POS_TOL and np.abs(q - qo).max() < Q_TOL
     ok = np.isfinite(pr).all(axis=(1, 2))
     assert (np.isfinite(pp).all(axis=(1, 2)) == ok).all() and ok.sum() >= nb // 3      # (short tracks lose their fit to the long outages: NaN rows on both sides)
     np.testing.assert_array_equal(stp[ok] & 0xff, str_[ok] & 0xff)
+    rowbits = (32 | 64 | 128) << 8
+    np.testing.assert_array_equal(stp & rowbits, str_ & rowbits)
+    np.testing.assert_array_equal((stp >> 8) & 1, (str_ >> 8) & 1)
     assert np.abs(pp[ok] - pr[ok]).max() < POS_TOL and np.abs(qp[ok] - qr[ok]).max() < 1e-8
     np.testing.assert_allclose(R.cpu().numpy()[ok], Rr[ok], atol=1e-9, rtol=0)
 

@@ -225,6 +225,7 @@ def test_robust_chain_on_stacked_copies_equals_main_process_gui(B, golden):
     golden run: each copy reproduces what the reference's main_process_gui computed end to end -- rows, R, t, s, Sim3 of pose 0 is
     implied, fused poses (<= 1e-7 m) -- and leaves the generator where np.random is after the reference's draws; the failing case
     leaves its generator untouched (the reference raises before it draws, :975)."""
+    import torch
     from gps_optimize_slam_amd import ekfgpsslam as E
     g, names = cases(golden)
     copies = 5
@@ -235,7 +236,29 @@ def test_robust_chain_on_stacked_copies_equals_main_process_gui(B, golden):
         batch = B.TrajectoryBatch.from_host(rep(ts), rep(pos), rep(quat), rep(al), rep(va), rep(pos[0]), rep(quat[0]), layout=0)
         seed = int(g[f"{n}_seed"])
         st = B.mt19937_seed([seed] * copies)
-        out, R, t, s, nin, mask = B.fuse_pipeline_robust_batch(batch, st, cfg, fit_rows="reference")
+        out, R, t, s, nin, mask, info = B.fuse_pipeline_robust_batch(batch, st, cfg, fit_rows="reference", early_exit=False, return_info=True)
+        # ... and with the exact early exit (ref :413: a trial that counts every row cannot be replaced): every output word the same, only
+        # the generators stop earlier
+        st_e = B.mt19937_seed([seed] * copies)
+        out_e, R_e, t_e, s_e, nin_e, mask_e, info_e = B.fuse_pipeline_robust_batch(batch, st_e, cfg, fit_rows="reference", early_exit=True, return_info=True)
+        SAT = 256 << 8
+        for a, b_ in ((out.pos, out_e.pos), (out.quat, out_e.quat), (R, R_e), (t, t_e), (s, s_e)):
+            assert torch.equal(torch.nan_to_num(a, nan=-1.0).view(torch.int64), torch.nan_to_num(b_, nan=-1.0).view(torch.int64)), n
+        assert torch.equal(nin, nin_e) and torch.equal(mask, mask_e) and torch.equal(out.status, out_e.status & ~SAT), n
+        assert torch.equal(info[:, 0], info_e[:, 0]), n                                 # the same trial's inlier set was kept
+        sat = (out_e.status & SAT) != 0
+        if bool(g[f"{n}_failed"]):
+            assert not sat.any() and (info_e[:, 1] == 0).all(), n                       # the reference raises before it draws (:975)
+        else:
+            nrows, trials = len(g[f"{n}_sim3_idx"]), cfg["sim3_ransac"]["max_trials"]
+            # saturated <=> the kept trial counted every row AND lies inside the probe's 64 trials; such a track drew the probe's rounds up
+            # to the one holding that trial (1, 1, 2, 4, ... trials), every other track all max_trials
+            expect = (nin == nrows) & (info[:, 0] >= 0) & (info[:, 0] < 64)
+            assert torch.equal(sat, expect), n
+            d = info_e[:, 0].cpu().numpy()
+            round_end = np.array([1 if k < 1 else 2 if k < 2 else 2 ** (int(np.floor(np.log2(k))) + 1) for k in np.maximum(d, 0)])
+            drawn = torch.as_tensor(np.where(sat.cpu().numpy(), np.minimum(round_end, min(64, trials)), trials), dtype=torch.int32, device="cuda")
+            assert torch.equal(info_e[:, 1], drawn) and (info[:, 1] == trials).all(), (n, info_e[:, 1].tolist(), drawn.tolist())
         p, q, status = out.host_traj_major()
         R, t, s, mask = R.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy(), mask.cpu().numpy()
         np.random.seed(seed)
