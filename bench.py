@@ -488,7 +488,11 @@ def oracle_gate(np, torch, B, bt, pos_out, status, idx, fit_rows, R=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def worker(args):
+def setup(args):
+    """Process-level set-up of one rank: imports, device, process group, the library context with the run's options, the fields every
+    line carries.  Returns a namespace the per-workload functions share."""
+    import types
+
     import numpy as np
     import torch
 
@@ -542,57 +546,71 @@ def worker(args):
                      "build_warnings": open(warn_path).read().strip() if os.path.exists(warn_path) else None}
     if base["build"]["build_warnings"] and rank == 0:
         print("bench.py: BUILD WARNING -- " + base["build"]["build_warnings"], file=sys.stderr)
-    partial = {}                                   # what rank 0 prints if the run-wide deadline fires (N > 1 only)
+    x = types.SimpleNamespace(args=args, np=np, torch=torch, _lib=_lib, B=B, D=D, L=L, ctx=ctx, dev=dev, rank=rank, world=world, ngpu=ngpu,
+                              rehearsal=rehearsal, wl=wl, Bn=Bn, N=N, steps=steps, warmup=warmup, base=base, partial={}, run_deadline=None)
     if world > 1:
         import threading
 
-        def on_deadline():
+        def on_deadline():                         # what rank 0 prints if the run-wide deadline fires
             if rank == 0:
-                print(json.dumps(dict(base, **partial, deadline_exceeded=f"{args.deadline_s:.0f} s", value=partial.get("value"))), flush=True)
+                print(json.dumps(dict(base, **x.partial, deadline_exceeded=f"{args.deadline_s:.0f} s", value=x.partial.get("value"))), flush=True)
             os._exit(STALL_EXIT_CODE)
-        run_deadline = threading.Timer(args.deadline_s, on_deadline)
-        run_deadline.daemon = True
-        run_deadline.start()
+        x.run_deadline = threading.Timer(args.deadline_s, on_deadline)
+        x.run_deadline.daemon = True
+        x.run_deadline.start()
+    return x
 
-    # ------------------------------------------------------------------------------------------------ C5 as the headline
-    if args.workload == "c5":
-        chunk = args.chunk_traj or (32768 if not rehearsal else 1024)
-        def emit_c5(info):
-            if rank != 0:
-                return
-            done = [c for c in info.get("collect", {}).values() if "pass_ms" in c]
-            best = min(done, key=lambda c: c["pass_ms"]) if world > 1 and done else None
-            pass_ms = best["pass_ms"] if best else info["compute_only"]["ms"]
-            T = info["trajectories_per_gpu"]
-            co = info["compute_only"]
-            result = dict(base, value=world * T * N / (pass_ms * 1e-3), ms_per_step=pass_ms,
-                          config={"workload": wl["name"], "trajectories_per_gpu": T, "poses_per_trajectory": N, "chunk_trajectories": info["chunk_trajectories"],
-                                  "layout": "trajectory-major AoS (wave-per-trajectory scans)", "step": "one pass over the shard: per chunk fused pipeline"
-                                  + (" + all-gather of the chunk's poses (second stream, overlapped)" if world > 1 else ""),
-                                  "parallelism": f"trajectory-sharded x{world}" + (" (gloo rehearsal on shared GPUs)" if rehearsal else "")},
-                          roofline={"bound": "hbm", "kernel": "ekf_wave_big_kernel<true, 1>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": co["hbm_frac"], "traffic": None, "traffic_note": "no PMC pass at this size", "alg_bytes_per_launch": info["chunk_trajectories"] * N * ALG_BYTES_PER_POSE,
-                                    "kernel_ms": co["ms"] / info["chunks"]},
-                          c5=info)
-            print(json.dumps(result), flush=True)
-        info = run_c5(torch, B, D, rank, world, dev, rehearsal, Bn, chunk, N, passes=max(1, steps), stall_cb=emit_c5,
-                      stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
-        emit_c5(info)
-        if world > 1:
-            run_deadline.cancel()
-            torch.distributed.destroy_process_group()
-        return
 
-    # ------------------------------------------------------------------------------------------------ C2 / C3
-    time_major = args.layout == "time"
-    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=B.LAYOUT_TIME_MAJOR if time_major else B.LAYOUT_TRAJ_MAJOR, seed=SEED, traj0=rank * Bn)   # this rank's shard: ids [rank*B, (rank+1)*B)
+def finish(x):
+    if x.world > 1:
+        x.run_deadline.cancel()
+        x.torch.distributed.destroy_process_group()
+
+
+def headline_c5(x):
+    """--workload c5: the per-GPU shard of BASELINE configs[4] as the headline (chunked fuse + overlapped all-gather, run_c5)."""
+    args, world, N, wl = x.args, x.world, x.N, x.wl
+    chunk = args.chunk_traj or (32768 if not x.rehearsal else 1024)
+
+    def emit_c5(info):
+        if x.rank != 0:
+            return
+        done = [c for c in info.get("collect", {}).values() if "pass_ms" in c]
+        best = min(done, key=lambda c: c["pass_ms"]) if world > 1 and done else None
+        pass_ms = best["pass_ms"] if best else info["compute_only"]["ms"]
+        T = info["trajectories_per_gpu"]
+        co = info["compute_only"]
+        result = dict(x.base, value=world * T * N / (pass_ms * 1e-3), ms_per_step=pass_ms,
+                      config={"workload": wl["name"], "trajectories_per_gpu": T, "poses_per_trajectory": N, "chunk_trajectories": info["chunk_trajectories"],
+                              "layout": "trajectory-major AoS (wave-per-trajectory scans)", "step": "one pass over the shard: per chunk fused pipeline"
+                              + (" + all-gather of the chunk's poses (second stream, overlapped)" if world > 1 else ""),
+                              "parallelism": f"trajectory-sharded x{world}" + (" (gloo rehearsal on shared GPUs)" if x.rehearsal else "")},
+                      roofline={"bound": "hbm", "kernel": "ekf_wave_big_kernel<true, 1>", "achieved": co["alg_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": co["hbm_frac"], "traffic": None, "traffic_note": "no PMC pass at this size", "alg_bytes_per_launch": info["chunk_trajectories"] * N * ALG_BYTES_PER_POSE,
+                                "kernel_ms": co["ms"] / info["chunks"]},
+                      c5=info)
+        print(json.dumps(result), flush=True)
+    info = run_c5(x.torch, x.B, x.D, x.rank, world, x.dev, x.rehearsal, x.Bn, chunk, N, passes=max(1, x.steps), stall_cb=emit_c5,
+                  stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
+    emit_c5(info)
+
+
+def timed_steps(x):
+    """The timed region of the c2 / c3 headline: this rank's synthetic shard, W warm-up launches, then EXACTLY K launches of the step (one
+    hipGraph replay of them where the capture is allowed) + for N > 1 the one all-gather of the fused poses, bracketed by barrier + synchronize
+    on both sides.  Fills x with the batch, the outputs, the launcher, the elapsed times."""
+    import ctypes as C
+    args, torch, B, D, L, _lib, dev, world, Bn, N, steps = x.args, x.torch, x.B, x.D, x.L, x._lib, x.dev, x.world, x.Bn, x.N, x.steps
+    x.time_major = args.layout == "time"
+    batch = B.TrajectoryBatch.synthetic(Bn, N, layout=B.LAYOUT_TIME_MAJOR if x.time_major else B.LAYOUT_TRAJ_MAJOR, seed=SEED, traj0=x.rank * Bn)   # this rank's shard: ids [rank*B, (rank+1)*B)
     out = B.FusedPoses(batch.layout, Bn, N, dev)
     f = dict(dtype=torch.float64, device=dev)
-    import ctypes as C
     cfg = _lib.EkfConfig.from_config(B.CONFIG)
-    h, p = ctx.handle, B._p
+    h, p = x.ctx.handle, B._p
+    x.R = None
     if args.kernel == "pipeline":
         R, t, s = torch.empty((Bn, 9), **f), torch.empty((Bn, 3), **f), torch.empty((Bn,), **f)
+        x.R = R
 
         def launch(h=h):
             _lib.check(L.gsf_fuse_pipeline_batch_dev(h, batch.layout, p(batch.ts), p(batch.pos), p(batch.quat), p(batch.gps), p(batch.valid),
@@ -606,7 +624,7 @@ def worker(args):
     def collect():                              # the job's ONE collect: fused poses of every shard to every GPU (RCCL over xGMI)
         D.all_gather_flat(gathered, out.buf)
 
-    for _ in range(warmup):
+    for _ in range(x.warmup):
         launch()
     if world > 1:
         collect()                               # communicator set-up stays outside the timed region
@@ -673,16 +691,19 @@ def worker(args):
         launch_mode += f"; {rehearsals} untimed rehearsals of the region right before it"
     D.barrier(dev); torch.cuda.synchronize()
     el, (ev0, ev1, ev2) = region()
-    elapsed = D.max_over_ranks(el, dev)
-    kern_ms = ev0.elapsed_time(ev1) / steps     # back-to-back launches of the one kernel: span / K = average launch duration
-    collect_ms = ev1.elapsed_time(ev2) if world > 1 else 0.0
-    poses_per_step = world * Bn * N
-    alg_bytes = Bn * N * ALG_BYTES_PER_POSE
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    # which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; both produce identical bits)
+    x.elapsed = D.max_over_ranks(el, dev)
+    x.kern_ms = ev0.elapsed_time(ev1) / steps     # back-to-back launches of the one kernel: span / K = average launch duration
+    x.collect_ms = ev1.elapsed_time(ev2) if world > 1 else 0.0
+    x.batch, x.out, x.launch, x.collect, x.gathered, x.launch_mode, x.f = batch, out, launch, collect, gathered, launch_mode, f
+
+
+def launched_kernel(x):
+    """Which build the library launches for this shape (gsf_ekf_wave.hip: launch_ekf_wave; all produce identical bits) -> its name and grid as
+    rocprofv3 reports them, and the section of the committed PMC profile that holds it."""
+    args, Bn, N = x.args, x.Bn, x.N
     pipe = args.kernel == "pipeline"
-    blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024 and not (args.kernel == "pipeline" and args.fit_rows == "reference")   # (its fit sees every valid row only)
-    lane_route = time_major and Bn >= 32768 and not any(kv.replace(" ", "").startswith("lane_min_traj=") for kv in args.set_option)
+    blk = any(kv.replace(" ", "") == "block_kernel=1" for kv in args.set_option) and 64 < N <= 1024   # (under --fit-rows reference its launcher marks the rows with sim3_rows_kernel first)
+    lane_route = x.time_major and Bn >= 32768 and not any(kv.replace(" ", "").startswith("lane_min_traj=") for kv in args.set_option)
     if lane_route:
         # lane per trajectory (gsf_ekf.hip): <LAYOUT, prefetch depth, waves per SIMD>
         kernel_name, grid_threads = ("fuse_pipeline_kernel<1, 2, 2>" if pipe else "ekf_fuse_kernel<1, 2, 2>"), ((Bn + 63) // 64) * 64
@@ -707,13 +728,26 @@ def worker(args):
         wl_key += f"_n{N}"                                                  # not a BASELINE configuration: never matches a committed section
     elif args.traj_per_gpu and args.workload == "c3" and Bn == 32768:
         wl_key = "c5chunk" + ("" if pipe else "ekf")                       # one chunk of the C5 shard: the grid the 38 launches of a pass have
+    x.lane_route = lane_route
+    return kernel_name, grid_threads, wl_key
+
+
+def headline_result(x):
+    """The contract line of the c2 / c3 headline from the timed region: value, config, roofline (algorithmic bytes per launch / the kernel's
+    live average duration; counter traffic and the issue-side floor from the committed PMC profile of the same kernel sources)."""
+    args, world, Bn, N, steps = x.args, x.world, x.Bn, x.N, x.steps
+    kern_ms = x.kern_ms
+    x.poses_per_step = world * Bn * N
+    x.alg_bytes = alg_bytes = Bn * N * ALG_BYTES_PER_POSE
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    kernel_name, grid_threads, wl_key = launched_kernel(x)
     traffic, traffic_src = profiled_traffic(wl_key, kernel_name, grid_threads)
-    result = dict(base, value=poses_per_step * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
-                  config={"workload": wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N,
-                          "layout": ("time-major SoA (" + ("lane per trajectory" if lane_route else "transposed, then wave per trajectory") + ")") if time_major
+    result = dict(x.base, value=x.poses_per_step * steps / x.elapsed, ms_per_step=x.elapsed / steps * 1e3,
+                  config={"workload": x.wl["name"], "trajectories_per_gpu": Bn, "poses_per_trajectory": N,
+                          "layout": ("time-major SoA (" + ("lane per trajectory" if x.lane_route else "transposed, then wave per trajectory") + ")") if x.time_major
                           else "trajectory-major AoS (wave-per-trajectory scans)",
-                          "step": args.kernel, "launch_mode": launch_mode, "parallelism": f"trajectory-sharded x{world}" + (", one RCCL all-gather of the fused poses after the K steps (inside the timed region)" if world > 1 else "")
-                          + (" (gloo rehearsal on shared GPUs)" if rehearsal else "")},
+                          "step": args.kernel, "launch_mode": x.launch_mode, "parallelism": f"trajectory-sharded x{world}" + (", one RCCL all-gather of the fused poses after the K steps (inside the timed region)" if world > 1 else "")
+                          + (" (gloo rehearsal on shared GPUs)" if x.rehearsal else "")},
                   roofline={"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                             "kernel_source_hash": kernel_source_hash()})
@@ -740,135 +774,175 @@ def worker(args):
             result["roofline"]["bound_note"] = ("the bytes the counters saw, at the rate apply_sim3_kernel moves the same 24 / 32-byte-stride rows (mixed read + write), "
                                                 "take a larger share of the kernel time than the VALU issue floor; achieved / peak / frac stay the algorithmic bytes at 8 TB/s")
     if args.kernel == "pipeline":
-        torch.cuda.synchronize()
+        x.torch.cuda.synchronize()
         # how many tracks of the timed batch took the Jacobi-SVD fallback of the fit (status bit GSF_SIM3_FLAG_SVD_FALLBACK << 8): one such
         # track costs its whole launch the SVD's time again, so the rate belongs next to the kernel time
-        result["fit_fallbacks"] = int(((out.status >> 8) & 16).ne(0).sum().item())
-        result["fit_none"] = int(((out.status >> 8) & 1).ne(0).sum().item())
+        result["fit_fallbacks"] = int(((x.out.status >> 8) & 16).ne(0).sum().item())
+        result["fit_none"] = int(((x.out.status >> 8) & 1).ne(0).sum().item())
         # the fused pipeline MOVES 194 B/pose (the fit pass re-reads pos/gps/valid: L2/Infinity-Cache hits at C2, real HBM traffic at C3)
         moved = Bn * N * (ALG_BYTES_PER_POSE + FIT_REREAD_BYTES_PER_POSE)
         result["roofline"]["moved_bytes_per_launch_incl_fit_pass"] = moved
         result["roofline"]["frac_of_peak_on_moved_bytes"] = moved / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    if world > 1:
-        # the collect, reported on its own (compute-only and compute+gather separately)
-        recv = (world - 1) * Bn * N * 56
-        k2 = max(1, min(steps, 20))
-        D.barrier(dev); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            launch(); collect()
-        torch.cuda.synchronize(); D.barrier(dev)
-        el2 = D.max_over_ranks(time.perf_counter() - t1, dev)
-        # gathered == the unsharded result?  rank r's block must equal what rank r computed (checksums travel by all_gather)
-        mine = out.buf.view(torch.int64).sum().reshape(1)
-        allsums = torch.empty((world,), dtype=torch.int64, device=dev)
-        D.all_gather_flat(allsums, mine)
-        blocks = gathered.view(world, -1).view(torch.int64).sum(dim=1)
-        result["collect"] = {"allgather_ms": collect_ms, "recv_bytes_per_rank": recv, "recv_GBps_per_rank": recv / (collect_ms * 1e-3) / 1e9 if collect_ms > 0 else None,
-                             "per_link_GBps": recv / (collect_ms * 1e-3) / 1e9 / (world - 1) if collect_ms > 0 else None,
-                             "compute_only_poses_per_s": world * Bn * N / (kern_ms * 1e-3),
-                             "collect_every_step": {"steps": k2, "ms_per_step": el2 / k2 * 1e3, "poses_per_s": poses_per_step * k2 / el2},
-                             "gathered_blocks_equal_rank_checksums": bool(torch.equal(blocks, allsums)),
-                             "backend": torch.distributed.get_backend()}
-    partial.update(result)
-    # ---- accuracy gate on THIS run: the timed `out` buffers (a sample SPREAD over the timed batch) against the CPU oracle on the same inputs
-    if rank == 0:
-        from oracle import oracle as orc
-        idx = spread_sample(Bn, 64)
-        nb = len(idx)
+    return result
+
+
+def collect_report(x):
+    """N > 1: the job's one collect on its own (compute-only and compute+gather separately), the rate with a gather after every
+    step, and that every gathered block equals its rank's own checksum."""
+    torch, D, dev, world, Bn, N, steps = x.torch, x.D, x.dev, x.world, x.Bn, x.N, x.steps
+    recv = (world - 1) * Bn * N * 56
+    k2 = max(1, min(steps, 20))
+    D.barrier(dev); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(k2):
+        x.launch(); x.collect()
+    torch.cuda.synchronize(); D.barrier(dev)
+    el2 = D.max_over_ranks(time.perf_counter() - t1, dev)
+    # gathered == the unsharded result?  rank r's block must equal what rank r computed (checksums travel by all_gather)
+    mine = x.out.buf.view(torch.int64).sum().reshape(1)
+    allsums = torch.empty((world,), dtype=torch.int64, device=dev)
+    D.all_gather_flat(allsums, mine)
+    blocks = x.gathered.view(world, -1).view(torch.int64).sum(dim=1)
+    cms = x.collect_ms
+    return {"allgather_ms": cms, "recv_bytes_per_rank": recv, "recv_GBps_per_rank": recv / (cms * 1e-3) / 1e9 if cms > 0 else None,
+            "per_link_GBps": recv / (cms * 1e-3) / 1e9 / (world - 1) if cms > 0 else None,
+            "compute_only_poses_per_s": world * Bn * N / (x.kern_ms * 1e-3),
+            "collect_every_step": {"steps": k2, "ms_per_step": el2 / k2 * 1e3, "poses_per_s": x.poses_per_step * k2 / el2},
+            "gathered_blocks_equal_rank_checksums": bool(torch.equal(blocks, allsums)),
+            "backend": torch.distributed.get_backend(),
+            "share_of_the_timed_region": cms / (cms + x.kern_ms * steps) if cms > 0 else None,
+            "how_to_read_value": (f"the timed region is the {steps} steps ({x.kern_ms * steps:.3f} ms of kernels) plus this ONE all-gather ({cms:.3f} ms, "
+                                  f"{recv / 1e6:.1f} MB received per rank): at small K the N > 1 `value` is the collect's time, not the kernels' -- "
+                                  "compute_only_poses_per_s is the kernels alone, collect_every_step the rate with a gather after every step")}
+
+
+def accuracy_gate(x, result):
+    """The accuracy gate on THIS run (rank 0): the timed `out` buffers of a sample SPREAD over the timed batch against the CPU oracle on the same
+    inputs -- ATE RMSE, max |dp|, status words -- and the reference's own error metric (Q15) of both results against the synthetic GNSS."""
+    from oracle import oracle as orc
+    args, np, torch, B, L, _lib, dev, Bn, N, out, f = x.args, x.np, x.torch, x.B, x.L, x._lib, x.dev, x.Bn, x.N, x.out, x.f
+    p = B._p
+    idx = spread_sample(Bn, 64)
+    nb = len(idx)
+    torch.cuda.synchronize()
+    ix = torch.as_tensor(idx, device=dev)
+    gb_ = x.batch.to_layout(B.LAYOUT_TRAJ_MAJOR)                          # (the gate reads trajectory-major views; a no-op for the default layout)
+    if x.time_major:
+        opos, oquat = torch.empty((Bn, N, 3), **f), torch.empty((Bn, N, 4), **f)
+        _lib.check(L.gsf_transpose_to_traj_major_dev(x.ctx.handle, p(out.pos), p(opos), Bn, N, 3, 8))
+        _lib.check(L.gsf_transpose_to_traj_major_dev(x.ctx.handle, p(out.quat), p(oquat), Bn, N, 4, 8))
         torch.cuda.synchronize()
-        ix = torch.as_tensor(idx, device=dev)
-        gb_ = batch.to_layout(B.LAYOUT_TRAJ_MAJOR)                          # (the gate reads trajectory-major views; a no-op for the default layout)
-        if time_major:
-            opos, oquat = torch.empty((Bn, N, 3), **f), torch.empty((Bn, N, 4), **f)
-            _lib.check(L.gsf_transpose_to_traj_major_dev(ctx.handle, p(out.pos), p(opos), Bn, N, 3, 8))
-            _lib.check(L.gsf_transpose_to_traj_major_dev(ctx.handle, p(out.quat), p(oquat), Bn, N, 4, 8))
-            torch.cuda.synchronize()
-        else:
-            opos, oquat = out.pos, out.quat
-        hh = {k: getattr(gb_, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
-        pg, qg, sg = opos.index_select(0, ix).cpu().numpy(), oquat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
-        result["gate_sample"] = f"{nb} trajectories of the timed batch: ids {int(idx[0])}..{int(idx[nb // 3 - 1])}, {int(idx[nb // 3])}..{int(idx[2 * (nb // 3) - 1])}, {int(idx[2 * (nb // 3)])}..{int(idx[-1])}"
-        if args.kernel == "pipeline":
-            po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], fit_rows=args.fit_rows)
-            rows_txt = ("the rows main_process_gui hands to its fit, EKFGPSSLAM.py:973-998" if args.fit_rows == "reference" else "every row with valid finite GNSS")
-            result["gated"] = f"timed fused-pipeline outputs (Umeyama on {rows_txt} -> Sim3 of pose 0 -> EKF+RTS) vs oracle.fuse_pipeline_batch(fit_rows='{args.fit_rows}')"
-            result["max_abs_sim3_R_err"] = float(np.nanmax(np.abs(R.index_select(0, ix).cpu().numpy() - Ro)))
-            result["fit_status_words_equal"] = bool((((sg >> 8) & ~16) == (sto >> 8)).all())
-        else:
-            po, qo, sto = orc.fuse_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], hh["init_pos"], hh["init_quat"])
-            result["gated"] = "timed K4 outputs vs oracle.fuse_batch"
-        fin = np.isfinite(po).all(axis=(1, 2))
-        result["ate_rmse_vs_cpu_ref_m"] = float(np.sqrt(np.mean(np.sum((pg[fin] - po[fin]) ** 2, axis=2))))
-        result["max_abs_pos_err_m"] = float(np.abs(pg[fin] - po[fin]).max())
-        result["max_abs_quat_err"] = float(np.abs(qg[fin] - qo[fin]).max())
-        result["status_bits_equal"] = bool(((sg & 0xff) == (sto & 0xff)).all()) and bool((np.isfinite(pg).all(axis=(1, 2)) == fin).all())
-        # the reference's own error metric (Q15, EKFGPSSLAM.py:1013-1033) of both results against the synthetic GNSS
-        stats, _ = B.eval_errors_batch(gb_.ts.index_select(0, ix), opos.index_select(0, ix).contiguous(), gb_.gps.index_select(0, ix),
-                                       gb_.valid.index_select(0, ix), 5.0)
-        del gb_, opos, oquat
-        g_rmse = stats[:, 3].cpu().numpy()
-        c_rmse = np.array([orc.evaluate_trajectory_errors(hh["ts"][b], po[b], hh["gps"][b], hh["valid"][b])["rmse"] for b in range(nb)])
-        both = np.isfinite(g_rmse) & np.isfinite(c_rmse)
-        result["ref_style_error_q15"] = {"gpu_rmse_m_mean": float(g_rmse[both].mean()), "cpu_rmse_m_mean": float(c_rmse[both].mean()),
-                                         "max_abs_diff_m": float(np.abs(g_rmse[both] - c_rmse[both]).max()), "trajectories": int(both.sum()),
-                                         "definition": "min distance to any candidate fix after the first 5 s, RMSE per trajectory (EKFGPSSLAM.py:1013-1033)"}
-    # ---- both definitions of the fit's rows in one line: the headline above is --fit-rows; here the other one, same batch, same box
+    else:
+        opos, oquat = out.pos, out.quat
+    hh = {k: getattr(gb_, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid", "init_pos", "init_quat")}
+    pg, qg, sg = opos.index_select(0, ix).cpu().numpy(), oquat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
+    result["gate_sample"] = f"{nb} trajectories of the timed batch: ids {int(idx[0])}..{int(idx[nb // 3 - 1])}, {int(idx[nb // 3])}..{int(idx[2 * (nb // 3) - 1])}, {int(idx[2 * (nb // 3)])}..{int(idx[-1])}"
+    if args.kernel == "pipeline":
+        po, qo, sto, Ro, to, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], fit_rows=args.fit_rows)
+        rows_txt = ("the rows main_process_gui hands to its fit, EKFGPSSLAM.py:973-998" if args.fit_rows == "reference" else "every row with valid finite GNSS")
+        result["gated"] = f"timed fused-pipeline outputs (Umeyama on {rows_txt} -> Sim3 of pose 0 -> EKF+RTS) vs oracle.fuse_pipeline_batch(fit_rows='{args.fit_rows}')"
+        result["max_abs_sim3_R_err"] = float(np.nanmax(np.abs(x.R.index_select(0, ix).cpu().numpy() - Ro)))
+        result["fit_status_words_equal"] = bool((((sg >> 8) & ~16) == (sto >> 8)).all())
+    else:
+        po, qo, sto = orc.fuse_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"], hh["init_pos"], hh["init_quat"])
+        result["gated"] = "timed K4 outputs vs oracle.fuse_batch"
+    fin = np.isfinite(po).all(axis=(1, 2))
+    result["ate_rmse_vs_cpu_ref_m"] = float(np.sqrt(np.mean(np.sum((pg[fin] - po[fin]) ** 2, axis=2))))
+    result["max_abs_pos_err_m"] = float(np.abs(pg[fin] - po[fin]).max())
+    result["max_abs_quat_err"] = float(np.abs(qg[fin] - qo[fin]).max())
+    result["status_bits_equal"] = bool(((sg & 0xff) == (sto & 0xff)).all()) and bool((np.isfinite(pg).all(axis=(1, 2)) == fin).all())
+    # the reference's own error metric (Q15, EKFGPSSLAM.py:1013-1033) of both results against the synthetic GNSS
+    stats, _ = B.eval_errors_batch(gb_.ts.index_select(0, ix), opos.index_select(0, ix).contiguous(), gb_.gps.index_select(0, ix),
+                                   gb_.valid.index_select(0, ix), 5.0)
+    del gb_, opos, oquat
+    g_rmse = stats[:, 3].cpu().numpy()
+    c_rmse = np.array([orc.evaluate_trajectory_errors(hh["ts"][b], po[b], hh["gps"][b], hh["valid"][b])["rmse"] for b in range(nb)])
+    both = np.isfinite(g_rmse) & np.isfinite(c_rmse)
+    result["ref_style_error_q15"] = {"gpu_rmse_m_mean": float(g_rmse[both].mean()), "cpu_rmse_m_mean": float(c_rmse[both].mean()),
+                                     "max_abs_diff_m": float(np.abs(g_rmse[both] - c_rmse[both]).max()), "trajectories": int(both.sum()),
+                                     "definition": "min distance to any candidate fix after the first 5 s, RMSE per trajectory (EKFGPSSLAM.py:1013-1033)"}
+
+
+def other_rows_report(x):
+    """Both definitions of the fit's rows in one line: the headline is --fit-rows; here the other one, same batch, same box."""
+    args, torch, B, world, Bn, N, out, R = x.args, x.torch, x.B, x.world, x.Bn, x.N, x.out, x.R
+    other = "all" if args.fit_rows == "reference" else "reference"
+    torch.cuda.synchronize()
+    st_head = out.status.clone(); R_head = R.clone()
+    x.ctx.set_sim3_rows(other, B.CONFIG)
+    k3 = max(20, min(x.steps, 100))                                       # few launches: the kernel trace of this command averages over them too
+    for _ in range(10):
+        x.launch()
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ea.record()
+    for _ in range(k3):
+        x.launch()
+    eb.record(); torch.cuda.synchronize()
+    ms_other = ea.elapsed_time(eb) / k3
+    changed = int((R_head - R).abs().amax(dim=1).gt(0).sum().item())
+    rows_bits = (st_head >> 8) if args.fit_rows == "reference" else (out.status >> 8)
+    rep = {"headline": args.fit_rows,
+           "definitions": {"reference": "the rows main_process_gui hands to its fit (EKFGPSSLAM.py:973-998): first gap-free segment of the valid rows, "
+                                        "<= max_initial_duration, fall-backs :984-986 / :993-995",
+                           "all": "every row with valid finite GNSS (the operator SURVEY 8(b)/(d) defined; rounds 1-3)"},
+           "other": {"fit_rows": other, "kernel_ms": ms_other, "value": world * Bn * N / (ms_other * 1e-3), "launch_mode": f"{k3} eager launches",
+                     "hbm_frac": x.alg_bytes / (ms_other * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "tracks_whose_fit_differs_between_the_two": changed, "tracks": Bn,
+           "reference_rule_branches": {"first_segment_too_short_all_rows": int(((rows_bits & 64) != 0).sum().item()),
+                                       "duration_limit_dropped_whole_segment": int(((rows_bits & 128) != 0).sum().item()),
+                                       "too_few_rows_value_error": int(((rows_bits & 32) != 0).sum().item())}}
+    x.ctx.set_sim3_rows(args.fit_rows, B.CONFIG)
+    x.launch(); torch.cuda.synchronize()                                  # leave the headline definition's outputs in `out` for the extras
+    return rep
+
+
+def c5_leg(x, result):
+    """N > 1: the C5-shaped leg next to the headline (BASELINE configs[4]): the per-GPU shard of 10M x 1k over 8 GPUs, chunked fuse + overlapped
+    all-gather."""
+    args = x.args
+    tpg = args.traj_per_gpu or (WORKLOADS["c5"]["B"] if not x.rehearsal else 4096)
+    chunk = args.chunk_traj or (32768 if not x.rehearsal else 1024)
+
+    def emit_with_c5(info):
+        if x.rank == 0:
+            result["c5"] = info
+            print(json.dumps(result), flush=True)
+    try:
+        info = run_c5(x.torch, x.B, x.D, x.rank, x.world, x.dev, x.rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5,
+                      stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
+    except Exception as e:                  # sizes are symmetric over ranks, so a failure (e.g. out of memory) is too
+        info = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return info
+
+
+def worker(args):
+    x = setup(args)
+    if args.workload == "c5":
+        headline_c5(x)
+        finish(x)
+        return
+    timed_steps(x)
+    result = headline_result(x)
+    if x.world > 1:
+        result["collect"] = collect_report(x)
+    x.partial.update(result)
+    if x.rank == 0:
+        accuracy_gate(x, result)
     if args.kernel == "pipeline" and not args.no_other_rows:
-        other = "all" if args.fit_rows == "reference" else "reference"
-        torch.cuda.synchronize()
-        st_head = out.status.clone(); R_head = R.clone()
-        ctx.set_sim3_rows(other, B.CONFIG)
-        k3 = max(20, min(steps, 100))                                       # few launches: the kernel trace of this command averages over them too
-        for _ in range(10):
-            launch()
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        ea.record()
-        for _ in range(k3):
-            launch()
-        eb.record(); torch.cuda.synchronize()
-        ms_other = ea.elapsed_time(eb) / k3
-        changed = int((R_head - R).abs().amax(dim=1).gt(0).sum().item())
-        rows_bits = (st_head >> 8) if args.fit_rows == "reference" else (out.status >> 8)
-        result["fit_rows"] = {"headline": args.fit_rows,
-                              "definitions": {"reference": "the rows main_process_gui hands to its fit (EKFGPSSLAM.py:973-998): first gap-free segment of the valid rows, "
-                                                           "<= max_initial_duration, fall-backs :984-986 / :993-995",
-                                              "all": "every row with valid finite GNSS (the operator SURVEY 8(b)/(d) defined; rounds 1-3)"},
-                              "other": {"fit_rows": other, "kernel_ms": ms_other, "value": world * Bn * N / (ms_other * 1e-3), "launch_mode": f"{k3} eager launches",
-                                        "hbm_frac": alg_bytes / (ms_other * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                              "tracks_whose_fit_differs_between_the_two": changed, "tracks": Bn,
-                              "reference_rule_branches": {"first_segment_too_short_all_rows": int(((rows_bits & 64) != 0).sum().item()),
-                                                          "duration_limit_dropped_whole_segment": int(((rows_bits & 128) != 0).sum().item()),
-                                                          "too_few_rows_value_error": int(((rows_bits & 32) != 0).sum().item())}}
-        ctx.set_sim3_rows(args.fit_rows, B.CONFIG)
-        launch(); torch.cuda.synchronize()                                 # leave the headline definition's outputs in `out` for the extras
-    # ---- extras (rank 0, N=1): PCIe-inclusive rate, the HBM-regime config, the drop-in's single-run latency
-    if world == 1 and not args.no_extra and not time_major:
-        result["extra"] = extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args)
-    del batch, out
-    torch.cuda.empty_cache()
-    if world > 1 and not args.no_extra:
-        # C5-shaped leg (BASELINE configs[4]): the per-GPU shard of 10M x 1k over 8 GPUs, chunked fuse + overlapped all-gather
-        tpg = args.traj_per_gpu or (WORKLOADS["c5"]["B"] if not rehearsal else 4096)
-        chunk = args.chunk_traj or (32768 if not rehearsal else 1024)
-        def emit_with_c5(info):
-            if rank == 0:
-                result["c5"] = info
-                print(json.dumps(result), flush=True)
-        try:
-            info = run_c5(torch, B, D, rank, world, dev, rehearsal, tpg, chunk, WORKLOADS["c5"]["N"], stall_cb=emit_with_c5,
-                          stall_seconds=args.stall_seconds, inject_stall_s=args.inject_stall, fit_rows=args.fit_rows)
-        except Exception as e:                  # sizes are symmetric over ranks, so a failure (e.g. out of memory) is too
-            info = {"error": f"{type(e).__name__}: {e}"[:300]}
-        result["c5"] = info
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(B, N, fit_rows=args.fit_rows)
-    if rank == 0:
+        result["fit_rows"] = other_rows_report(x)
+    # extras (rank 0, N=1): PCIe-inclusive rate, the HBM-regime config, the robust and the whole-run chains, the drop-in's single-run latency
+    if x.world == 1 and not args.no_extra and not x.time_major:
+        result["extra"] = extras(x.torch, x.B, x.L, x.ctx, x.batch, x.out, x.launch, x.Bn, x.N, x.dev, args)
+    x.batch = x.out = x.launch = x.collect = x.gathered = x.R = None
+    x.torch.cuda.empty_cache()
+    if x.world > 1 and not args.no_extra:
+        result["c5"] = c5_leg(x, result)
+    if x.rank == 0 and x.world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(x.B, x.N, fit_rows=args.fit_rows)
+    if x.rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        run_deadline.cancel()
-        torch.distributed.destroy_process_group()
+    finish(x)
 
 
 def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
@@ -981,12 +1055,14 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
         extra["geodetic_chain_c2"] = {"ms": ms_g, "poses_per_s": 271e3 / ms_g * 1e3, "gnss_fixes": int(gb.gps_t.numel()),
                                       "stages": "gsf_gps_rows_to_utm_batch_dev -> gsf_time_align_batch_dev -> gsf_fuse_pipeline_batch_dev"}
         del gb, og
+        extra["full_chain_c2"] = full_chain(torch, np, B, timed, dev, 1000, 271)
         extra["robust_chain_c2"] = robust_chain(torch, np, B, timed, dev, 1000, 271, args.fit_rows, parity=32)
         extra["robust_chain_8192"] = robust_chain(torch, np, B, timed, dev, 8192, 271, args.fit_rows, parity=0)
         a_, b_ = extra["robust_chain_c2"], extra["robust_chain_8192"]
         if "ms" in a_ and "ms" in b_:
             b_["per_stream_cost_vs_1000_streams"] = (b_["ms"] / 8192) / (a_["ms"] / 1000)
             b_["draws_per_stream_cost_vs_1000_streams"] = (b_["draws_ms"] / 8192) / (a_["draws_ms"] / 1000)
+            b_["all_trials_per_stream_cost_vs_1000_streams"] = (b_["all_trials"]["ms"] / 8192) / (a_["all_trials"]["ms"] / 1000)
         extra["c1_drop_in"] = c1_latency(np)
         extra["fit_distributions_c2"] = fit_distributions(torch, np, B, timed, dev)
         extra["c4_1M_x_50"] = c4_windows(torch, B, timed)
@@ -996,28 +1072,54 @@ def extras(torch, B, L, ctx, batch, out, launch, Bn, N, dev, args):
 
 
 def robust_chain(torch, np, B, timed, dev, nb, N, fit_rows, parity=0):
-    """Steps 3-5 with the reference's ROBUST fit as one device chain at `nb` streams (EKFGPSSLAM.py:1002-1010, :389-426): wall time of the
-    chain and of its draws alone; with parity > 0 a sample of the TIMED run against the oracle fed with NumPy's own draws for the same seeds."""
+    """Steps 3-5 with the reference's ROBUST fit as one device chain at `nb` streams (EKFGPSSLAM.py:1002-1010, :389-426), in both modes: every
+    trajectory drawing all max_trials (its generator ends where np.random ends in the reference), and stopping at the first trial that counts
+    every row (ref :413; `ms`, the mode batch.py uses by default) -- same R / t / s / masks / poses bit for bit, checked here on the timed
+    outputs.  With parity > 0 a sample of the TIMED run against the oracle fed with NumPy's own draws for the same seeds."""
     from oracle import oracle as orc
     try:
         bt = B.TrajectoryBatch.synthetic(nb, N, layout=B.LAYOUT_TRAJ_MAJOR, seed=SEED)
         o = B.FusedPoses(bt.layout, nb, N, dev)
+        o_full = B.FusedPoses(bt.layout, nb, N, dev)
         st0 = B.mt19937_seed(np.arange(nb))
         sc = B.CONFIG["sim3_ransac"]
-        keep = [None]
+        keep, keep_full = [None], [None]
 
         def chain():
-            keep[0] = B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False, fit_rows=fit_rows)
-        ms_r = timed(chain, 5)
+            keep[0] = B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o, want_mask=False, fit_rows=fit_rows, early_exit=True, return_info=True)
+
+        def chain_full():
+            keep_full[0] = B.fuse_pipeline_robust_batch(bt, st0.clone(), out=o_full, want_mask=False, fit_rows=fit_rows, early_exit=False, return_info=True)
+        ms_full = timed(chain_full, 5)
+        ms_r = timed(chain, 20)
         npop = [N] * nb                                                    # (host values: the library then knows the largest population)
         ms_d = timed(lambda: B.mt19937_choice_batch(st0.clone(), npop, sc["max_trials"], sc["min_samples"]), 5)
+        torch.cuda.synchronize()
+        (oe, Re, te, se, nine, _, infoe), (of, Rf, tf, sf, ninf, _, infof) = keep[0], keep_full[0]
+        sat = ((oe.status >> 8) & 256) != 0
+        same = all(torch.equal(torch.nan_to_num(a, nan=-1.0).view(torch.int64), torch.nan_to_num(b_, nan=-1.0).view(torch.int64))
+                   for a, b_ in ((oe.pos, of.pos), (oe.quat, of.quat), (Re, Rf), (te, tf), (se, sf)))
+        same = same and bool(torch.equal(nine, ninf)) and bool(torch.equal(oe.status & ~(256 << 8), of.status)) and bool(torch.equal(infoe[:, 0], infof[:, 0]))
+        drawn = infoe[:, 1].long()
+        hist = torch.bincount(drawn[sat]) if bool(sat.any()) else torch.zeros(1, dtype=torch.long)
         res = {"ms": ms_r, "poses_per_s": nb * N / ms_r * 1e3, "streams": nb, "max_trials": sc["max_trials"], "fit_rows": fit_rows,
-               "ms_per_1000_streams": ms_r / nb * 1000, "draws_ms": ms_d, "draws_us_per_trial_step": ms_d * 1e3 / sc["max_trials"],
-               "draws_ns_per_stream_trial": ms_d * 1e6 / (nb * sc["max_trials"]),
-               "stages": "row choice -> compact -> mt19937 choice (1000 x permutation(n)[:4] per trajectory) -> K2b -> Sim3(pose 0) -> K4"}
+               "mode": "ransac_early_exit = 1 (batch.py's default): a trajectory stops at the first trial that counts every row (ref :413)",
+               "ms_per_1000_streams": ms_r / nb * 1000,
+               "all_trials": {"ms": ms_full, "poses_per_s": nb * N / ms_full * 1e3, "ms_per_1000_streams": ms_full / nb * 1000,
+                              "mode": "ransac_early_exit = 0: every trajectory draws max_trials; generators end where the reference leaves np.random"},
+               "speedup_over_all_trials": ms_full / ms_r,
+               "outputs_identical_in_both_modes": bool(same),
+               "saturated_trajectories": int(sat.sum().item()), "saturated_share": float(sat.double().mean().item()),
+               "trials_drawn_by_saturated_trajectories_histogram": {str(k): int(v) for k, v in enumerate(hist.tolist()) if v},
+               "unsaturated_trajectories_draw": sc["max_trials"],
+               "deciding_trial_max_among_saturated": int(infoe[sat, 0].max().item()) if bool(sat.any()) else None,
+               "draws_ms": ms_d, "draws_wall_us_per_trial_of_every_stream": ms_d * 1e3 / sc["max_trials"],
+               "draws_wall_ns_per_stream_and_trial": ms_d * 1e6 / (nb * sc["max_trials"]),
+               "stages": "row choice -> compact -> early-exit probe (rounds of 1, 1, 2, 4, ... drawn-and-scored trials per trajectory) -> mt19937 choice + K2b for "
+                         "the trials left of undecided trajectories -> Sim3(pose 0) -> K4"}
         if parity > 0:
             chain(); torch.cuda.synchronize()
-            out, R, t, s, nin, _ = keep[0]
+            out, R, t, s, nin, _, _ = keep[0]
             idx = spread_sample(nb, parity)
             ix = torch.as_tensor(idx, device=dev)
             hh = {k_: getattr(bt, k_).index_select(0, ix).cpu().numpy() for k_ in ("ts", "pos", "quat", "gps", "valid")}
@@ -1039,7 +1141,62 @@ def robust_chain(torch, np, B, timed, dev, nb, N, fit_rows, parity=0):
             res["parity_sample_vs_oracle"] = {"trajectories": int(len(idx)), "of_the_timed_run": True, "max_abs_pos_err_m": worst, "max_abs_sim3_R_err": rworst,
                                               "status_bits_equal": ok_status, "inlier_counts_equal": ok_count,
                                               "how": "oracle.compute_sim3_transform_robust fed np.random.choice draws of np.random.seed(trajectory id), rows by the same rule"}
-        del bt, o, st0
+        del bt, o, o_full, st0
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def full_chain(torch, np, B, timed, dev, nb, N):
+    """Steps 1-6 of main_process_gui (EKFGPSSLAM.py:959-1033) for `nb` trajectories as ONE device chain (gsf_run_fusion_batch_dev): geodesy slice
+    -> GPS RANSAC pre-filter (windows walked on the device) -> time alignment -> row choice -> robust Sim3 (early exit on) -> apply -> EKF + RTS
+    -> error metric; the reference-complete throughput figure next to the plain-fit headline.  Stage split: the stages timed on their own on the
+    same data (their sum is not the chain's time: launches overlap their tails)."""
+    import ctypes as C
+    from gps_optimize_slam_amd import _lib
+    try:
+        L, ctx = _lib.load(), B.context()
+        gb = B.GeodeticBatch.synthetic(nb, N, seed=SEED)
+        st0 = B.mt19937_seed(np.arange(nb) + 1)
+        keep = [None]
+
+        def chain():
+            keep[0] = B.run_fusion_batch(gb, st0.clone(), early_exit=True, want_mask=False)
+        ms = timed(chain, 10)
+        ms_full = timed(lambda: B.run_fusion_batch(gb, st0.clone(), early_exit=False, want_mask=False), 3)
+        torch.cuda.synchronize()
+        r = keep[0]
+        total = int(gb.gps_t.numel())
+        res = {"ms": ms, "poses_per_s": nb * N / ms * 1e3, "trajectories": nb, "poses": N, "gnss_fixes": total,
+               "all_trials_ms": ms_full, "all_trials_poses_per_s": nb * N / ms_full * 1e3,
+               "stages": "gsf_gps_rows_to_utm -> loader compaction -> gps_prefilter_chain (device-walked windows) -> filtered rows -> time_align -> sim3 rows -> "
+                         "compact -> early-exit probe (+ mt19937 choice + K2b for undecided tracks) -> Sim3(pose 0) -> K4 -> apply Sim3 (all poses) -> 3 x eval_errors",
+               "run_status_nonzero": int((r.run_status != 0).sum().item()), "saturated_share": float((((r.fused.status >> 8) & 256) != 0).double().mean().item()),
+               "fixes_kept_share": float(r.gps_keep.double().mean().item()),
+               "step6_rmse_m_mean": {"raw_slam": float(r.err_stats[0, :, 3].nanmean().item()), "sim3": float(r.err_stats[1, :, 3].nanmean().item()),
+                                     "ekf": float(r.err_stats[2, :, 3].nanmean().item())}}
+        # stage split, each on its own
+        f = dict(dtype=torch.float64, device=dev)
+        utm = torch.empty_like(gb.gps_llh); zone = torch.empty(nb, dtype=torch.int32, device=dev); south = torch.empty_like(zone)
+        split = {}
+        split["geodesy_slice_ms"] = timed(lambda: _lib.check(L.gsf_gps_rows_to_utm_batch_dev(ctx.handle, B._p(gb.gps_llh), B._p(gb.gps_offsets), nb, B._p(utm), B._p(zone), B._p(south))), 20)
+        pc = _lib.PrefilterConfig.from_config(B.CONFIG["gps_filtering_ransac"])
+        keepm = torch.empty(total, dtype=torch.uint8, device=dev); ls = torch.empty(nb, dtype=torch.int32, device=dev)
+        split["prefilter_ms"] = timed(lambda: _lib.check(L.gsf_gps_prefilter_auto_dev(ctx.handle, B._p(gb.gps_t), B._p(utm), B._p(gb.gps_offsets), nb, int(gb.max_fixes), C.byref(pc),
+                                                                                    B._p(st0.clone()), B._p(keepm), B._p(ls), None)), 10)
+        al = torch.empty((nb, N, 3), **f); va = torch.empty((nb, N), dtype=torch.uint8, device=dev)
+        split["time_alignment_ms"] = timed(lambda: _lib.check(L.gsf_time_align_loaded_rows_batch_dev(ctx.handle, B._p(gb.ts), B._p(gb.slam_offsets), B._p(gb.gps_t), B._p(utm),
+                                                                                                   B._p(gb.gps_offsets), nb, max(2, int(gb.max_fixes)), 5.0, B._p(al), B._p(va), None)), 20)
+        tb = B.TrajectoryBatch(B.LAYOUT_TRAJ_MAJOR, nb, N, dev)
+        tb.ts, tb.pos, tb.quat, tb.gps, tb.valid = gb.ts, gb.pos, gb.quat, r.aligned, r.valid
+        o = B.FusedPoses(B.LAYOUT_TRAJ_MAJOR, nb, N, dev)
+        split["robust_steps_3_to_5_ms"] = timed(lambda: B.fuse_pipeline_robust_batch(tb, st0.clone(), out=o, want_mask=False), 10)
+        split["apply_sim3_all_poses_ms"] = timed(lambda: B.apply_sim3_batch(gb.pos.view(-1, 3), gb.quat.view(-1, 4), gb.slam_offsets, r.R, r.t, r.s), 20)
+        split["error_metric_3_tracks_ms"] = 3 * timed(lambda: B.eval_errors_batch(gb.ts, r.fused.pos, r.aligned, r.valid, 5.0), 20)
+        res["stage_split"] = split
+        res["stage_split_sum_ms"] = sum(split.values())
+        del gb, r, o, tb
         torch.cuda.empty_cache()
         return res
     except Exception as e:
@@ -1169,7 +1326,7 @@ def c5_shard(torch, B, L, dev, timed, traj=1_245_184, N=1000, chunk=32768, fit_r
             ms = timed(one_pass, 3)
             res[lname] = {"pass_ms": ms, "poses_per_s": T * N / ms * 1e3, "alg_GBps": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
                           "launches_per_pass": T // chunk if lay == B.LAYOUT_TRAJ_MAJOR else 1,
-                          "fit_none": int((status >> 8).eq(1).sum().item()), "had_outage": int((status & 1).ne(0).sum().item()),
+                          "fit_none": int(((status >> 8) & 1).ne(0).sum().item()), "had_outage": int((status & 1).ne(0).sum().item()),
                           "rts_applied": int((status & 2).ne(0).sum().item()), "sharp_turn": int((status & 4).ne(0).sum().item())}
             if lay == B.LAYOUT_TRAJ_MAJOR:
                 # the timed outputs against the oracle: 64 trajectories from the first, a middle and the last chunk of the pass
@@ -1209,7 +1366,15 @@ def c1_latency(np):
         gold = os.path.join(ROOT, "tests", "golden")
         k, g = np.load(os.path.join(gold, "kat_bundled.npz")), np.load(os.path.join(gold, "c1_combined.npz"))
         slam = {"timestamps": k["ts"], "positions": k["pos"], "quaternions": k["quat"]}
-        return E.benchmark_c1(slam, g["gps_t_raw"], g["lat"], g["lon"], g["alt"], repeats=20)
+        res = E.benchmark_c1(slam, g["gps_t_raw"], g["lat"], g["lon"], g["alt"], repeats=20)
+        try:                                       # the reference on the same track, timed in the build container (tests/campaigns/time_reference.py)
+            prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_timing.json")))[-1]
+            c = json.load(open(prof))["cases"]["kitti04_vs_combined_gnss"]
+            res["reference_cpu_ms"] = {"steps_2_to_5": c["steps_2_to_5"]["reference_ms"], "compute_sim3_transform_robust": c["compute_sim3_transform_robust"]["reference_ms"],
+                                       "apply_ekf_correction": c["apply_ekf_correction"]["reference_ms"], "source": os.path.basename(prof) + " (the reference itself, 1 core)"}
+        except Exception as e:
+            res["reference_cpu_ms"] = {"error": str(e)[:120]}
+        return res
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 

@@ -195,13 +195,14 @@ class RunResult:
         self.__dict__.update(kw)
 
 
-def run_fusion_batch(gb, mt_state, config=None, early_exit=True, skip_seconds=5.0, max_windows=0, want_mask=True):
+def run_fusion_batch(gb, mt_state, config=None, early_exit=True, skip_seconds=5.0, max_windows=0, want_mask=True, projected=False):
     """Steps 1-6 of main_process_gui (EKFGPSSLAM.py:959-1033) for the B trajectories of a GeodeticBatch as ONE device chain on torch's
     current stream: load-side geodesy (:258-271) -> GPS RANSAC pre-filter with its windows walked on the device (:275, :136-247) ->
     time alignment (:971) -> row choice (:973-998) -> robust Sim3 (:1002) -> apply (:1006) -> EKF + RTS (:1010) -> error metric (:1013-1033).
     mt_state (B, 625): every trajectory's NumPy legacy generator (mt19937_seed / mt19937_from_numpy), advanced by the pre-filter's and
     the fit's draws in the reference's order; early_exit as in fuse_pipeline_robust_batch (the pre-filter's draws are unaffected).
-    Returns a RunResult."""
+    projected=True: gb.gps_llh already holds (E, N, alt) rows -- what load_gps_data's projection returns -- and the chain starts at the
+    pre-filter.  Returns a RunResult."""
     g = config or CONFIG
     ctx = context()
     ctx.set_option("ransac_early_exit", 1 if early_exit else 0)
@@ -212,12 +213,12 @@ def run_fusion_batch(gb, mt_state, config=None, early_exit=True, skip_seconds=5.
     total = int(gb.gps_t.numel())
     out = FusedPoses(LAYOUT_TRAJ_MAJOR, B, N, dev)
     r = RunResult(fused=out, R=torch.empty((B, 9), **f), t=torch.empty((B, 3), **f), s=torch.empty((B,), **f), n_inliers=torch.empty((B,), **i32),
-                  zone=torch.empty((B,), **i32), south=torch.empty((B,), **i32), gps_utm=torch.empty((total, 3), **f),
+                  zone=torch.empty((B,), **i32), south=torch.empty((B,), **i32), gps_utm=gb.gps_llh.clone() if projected else torch.empty((total, 3), **f),
                   gps_keep=torch.empty((total,), dtype=torch.uint8, device=dev), aligned=torch.empty((B, N, 3), **f),
                   valid=torch.empty((B, N), dtype=torch.uint8, device=dev), sim3_pos=torch.empty((B, N, 3), **f), err_stats=torch.empty((3, B, 4), **f),
                   run_status=torch.empty((B,), **i32), inlier_mask=torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None,
                   trial_info=torch.empty((B, 2), **i32))
-    check(_lib.load().gsf_run_fusion_batch_dev(ctx.handle, _p(gb.ts), _p(gb.pos), _p(gb.quat), B, N, _p(gb.gps_t), _p(gb.gps_llh), _p(gb.gps_offsets), total,
+    check(_lib.load().gsf_run_fusion_batch_dev(ctx.handle, _p(gb.ts), _p(gb.pos), _p(gb.quat), B, N, _p(gb.gps_t), None if projected else _p(gb.gps_llh), _p(gb.gps_offsets), total,
                                                int(gb.max_fixes), C.byref(rc), _p(mt_state), _p(r.R), _p(r.t), _p(r.s), _p(out.pos), _p(out.quat), _p(out.status),
                                                _p(r.n_inliers), _p(r.zone), _p(r.south), _p(r.gps_utm), _p(r.gps_keep), _p(r.aligned), _p(r.valid), _p(r.sim3_pos),
                                                _p(r.err_stats), _p(r.run_status), _p(r.inlier_mask), _p(r.trial_info)))

@@ -14,9 +14,9 @@
 // s_setprio(3) in the helper (mode 3) 20.1 us.  Two chunk loops inlined side by side instead of the run-time choice: 222 registers, 115 scalars
 // spilled into VGPR lanes, 24.1 us; the rare loop behind a call: 270 registers = one wave per SIMD, 34.3 us.  Not shipped.
 //
-// To build it, gsf_wave_common.hpp needs the run-time switch this file uses (it was reverted with the experiment so that the shipped sources
-// stay the profiled ones): `int32_t use_pv;` as last member of WaveArgs, and `if (PREVAR && (a).use_pv != 0) {` where wave_serial_chunks
-// chooses between the LDS variances and variance_chunk().
+// The run-time switch it needs in gsf_wave_common.hpp (`int32_t use_pv` as last member of WaveArgs, `PREVAR && a.use_pv` where
+// wave_serial_chunks chooses between the LDS variances and variance_chunk()) sits behind GSF_EXP_HYBRID, which only this file defines: the
+// shipped translation units compile the profiled sources unchanged.
 #define GSF_EXP_HYBRID 1
 #include <cstdlib>
 #include "../gsf_wave_common.hpp"

@@ -475,7 +475,7 @@ GSF_HD int32_t umeyama_finalize(const double* H, double ssq, const double* sc, c
 // WGS84 UTM, Krueger n-series to n^6 (replaces pyproj Proj("+proj=utm ..."), ref :267-270, :295)
 // ---------------------------------------------------------------------------------------
 struct TmConsts {
-    double e, k0A, alpha[6], beta[6];
+    double e, k0A, alpha[6], beta[6], delta[6];
 };
 GSF_HD TmConsts tm_consts()
 {
@@ -496,6 +496,14 @@ GSF_HD TmConsts tm_consts()
     c.beta[3] = 4397 * n4 / 161280 - 11 * n5 / 504 - 830251 * n6 / 7257600;
     c.beta[4] = 4583 * n5 / 161280 - 108847 * n6 / 3991680;
     c.beta[5] = 20648693 * n6 / 638668800;
+    // conformal (Gaussian) latitude chi -> geodetic latitude: phi = chi + sum_j delta_j sin(2 j chi), to n^6 (the series PROJ's extended
+    // transverse Mercator takes on its way back; truncation 8e-18 rad against a 50-digit evaluation, tests/golden/gen_utm_mpmath.py)
+    c.delta[0] = 2 * n - 2 * n2 / 3 - 2 * n3 + 116 * n4 / 45 + 26 * n5 / 45 - 2854 * n6 / 675;
+    c.delta[1] = 7 * n2 / 3 - 8 * n3 / 5 - 227 * n4 / 45 + 2704 * n5 / 315 + 2323 * n6 / 945;
+    c.delta[2] = 56 * n3 / 15 - 136 * n4 / 35 - 1262 * n5 / 105 + 73814 * n6 / 2835;
+    c.delta[3] = 4279 * n4 / 630 - 332 * n5 / 35 - 399572 * n6 / 14175;
+    c.delta[4] = 4174 * n5 / 315 - 144838 * n6 / 6237;
+    c.delta[5] = 601676 * n6 / 22275;
     return c;
 }
 
@@ -578,7 +586,9 @@ GSF_HD void utm_forward_point(const TmConsts& c, double lat_deg, double lon_deg,
                               double& easting, double& northing)
 {
     const double d2r = 0.017453292519943295769;
-    const double phi = lat_deg * d2r, lam = lon_deg * d2r - lon0_deg * d2r;
+    // (the difference is taken in DEGREES, where it is exact or nearly so -- lon0 is an integer --, and converted once: converting both
+    // longitudes first leaves 2e-16 x |lon| rad of rounding in a lambda of a few hundredths, 2.7e-9 m at zone 60; round 5)
+    const double phi = lat_deg * d2r, lam = (lon_deg - lon0_deg) * d2r;
     double sp, cp; gsf_sincos(phi, sp, cp);
     // (1/x and 1/sqrt(x) by hardware seed + Newton: every operand here is a normal number of moderate size)
     const double t1 = fast_rcp(cp), tau = sp * t1;            // sqrt(1 + tan^2), tan(phi)   (|phi| <= pi/2: cp > 0)
@@ -603,9 +613,13 @@ GSF_HD void utm_forward_point(const TmConsts& c, double lat_deg, double lon_deg,
 GSF_HD void sinh_cosh_small(double z, double& sh, double& ch)
 {
     if (fabs(z) < 0.5) {
+        // (Taylor coefficients as constants: the nested z2 / 6.0 * (1.0 + z2 / 20.0 * ...) form of rounds 1-4 cost fifteen float64 DIVISIONS per
+        // call -- two calls per inverse projection, ~25 instructions each -- and was what held K1 inverse at 1.8 x the forward time)
         const double z2 = z * z;
-        sh = z * (1.0 + z2 / 6.0 * (1.0 + z2 / 20.0 * (1.0 + z2 / 42.0 * (1.0 + z2 / 72.0 * (1.0 + z2 / 110.0 * (1.0 + z2 / 156.0 * (1.0 + z2 / 210.0)))))));
-        ch = 1.0 + z2 / 2.0 * (1.0 + z2 / 12.0 * (1.0 + z2 / 30.0 * (1.0 + z2 / 56.0 * (1.0 + z2 / 90.0 * (1.0 + z2 / 132.0 * (1.0 + z2 / 182.0 * (1.0 + z2 / 240.0)))))));
+        sh = z * (1.0 + z2 * (1.0 / 6 + z2 * (1.0 / 120 + z2 * (1.0 / 5040 + z2 * (1.0 / 362880 + z2 * (1.0 / 39916800 + z2 * (1.0 / 6227020800.0 +
+                 z2 * (1.0 / 1307674368000.0))))))));
+        ch = 1.0 + z2 * (1.0 / 2 + z2 * (1.0 / 24 + z2 * (1.0 / 720 + z2 * (1.0 / 40320 + z2 * (1.0 / 3628800 + z2 * (1.0 / 479001600.0 + z2 * (1.0 / 87178291200.0 +
+                   z2 * (1.0 / 20922789888000.0))))))));
     } else {
         const double ez = exp(z), ezi = 1.0 / ez;
         sh = 0.5 * (ez - ezi); ch = 0.5 * (ez + ezi);
@@ -626,21 +640,24 @@ GSF_HD void utm_inverse_point(const TmConsts& c, double easting, double northing
     double xip = xi - a, etap = eta - b;
     double sh, chd; sinh_cosh_small(etap, sh, chd);
     double sx, cx; gsf_sincos(xip, sx, cx);
-    double taup = sx * fast_rsqrt(sh * sh + cx * cx);
-    double lam = atan2(sh, cx);
-    double e2m = 1.0 - c.e * c.e;
-    const double ie2m = 1.0 / e2m;
-    double tau = taup * ie2m;
-    for (int it = 0; it < 6; ++it) {           // Newton on tau'(tau) (Karney 2011 eqs 19-21); converges in 2-3
-        const double ot2 = 1.0 + tau * tau, rt1 = fast_rsqrt(ot2), t1 = ot2 * rt1;          // 1/sqrt(1+tau^2), sqrt(1+tau^2)
-        const double sig = tm_sigma(c.e, tau * rt1);
-        const double os2 = 1.0 + sig * sig;
-        const double tpi = tau * (os2 * fast_rsqrt(os2)) - sig * t1;
-        const double dtau = (taup - tpi) * fast_rsqrt(1.0 + tpi * tpi) * (1.0 + e2m * tau * tau) * (ie2m * rt1);
-        tau += dtau;
-        if (!(fabs(dtau) > 1e-15 * (1.0 + fabs(tau)))) break;
+    const double lam = atan2(sh, cx);
+    // conformal latitude chi of the point: sin chi = sin xi' / cosh eta', cos chi = hypot(sinh eta', cos xi') / cosh eta' (the three squares
+    // add up to cosh^2 eta'), then the geodetic latitude by the direct series in n -- no iteration, no data-dependent exit inside a wave
+    // (rounds 1-4 solved tau'(tau) = tau' by Newton: up to six rounds with a divergent break, 2.59 ms per 1e8 points against 1.48 ms forward)
+    const double hyp2 = sh * sh + cx * cx;
+    const double hyp = hyp2 > 0.0 ? hyp2 * fast_rsqrt(hyp2) : 0.0;
+    const double ich = fast_rcp(chd);
+    const double sc = sx * ich, cc = hyp * ich;
+    const double chi = atan2(sx, hyp);
+    const double s2c = 2.0 * sc * cc, c2c = (cc - sc) * (cc + sc);
+    double sj = s2c, cj = c2c, dphi = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        dphi += c.delta[j] * sj;
+        const double sn = sj * c2c + cj * s2c, cn = cj * c2c - sj * s2c;
+        sj = sn; cj = cn;
     }
-    lat_deg = atan(tau) * r2d;
+    lat_deg = (chi + dphi) * r2d;
     lon_deg = lam * r2d + lon0_deg;
 }
 

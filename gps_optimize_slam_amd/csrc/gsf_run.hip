@@ -117,9 +117,9 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     GSF_REQUIRE(ctx && cfg, "ctx/cfg is NULL");
     GSF_REQUIRE(B >= 0 && N >= 0 && B <= 0x7fffffff && total_fixes >= 0 && max_fixes >= 0, "bad B, N, total_fixes or max_fixes");
     if (B == 0 || N == 0) return GSF_OK;
-    GSF_REQUIRE(ts && pos && quat && gps_offsets && mt_state && R && t && s && pos_out && quat_out && status && n_inliers && zone && south && aligned &&
-                valid && err_stats && run_status, "NULL array");
-    GSF_REQUIRE(total_fixes == 0 || (gps_t && gps_llh && gps_utm && gps_keep), "NULL GNSS array");
+    GSF_REQUIRE(ts && pos && quat && gps_offsets && mt_state && R && t && s && pos_out && quat_out && status && n_inliers && aligned && valid && err_stats &&
+                run_status && (!gps_llh || (zone && south)), "NULL array");
+    GSF_REQUIRE(total_fixes == 0 || (gps_t && gps_utm && gps_keep), "NULL GNSS array");
     GSF_REQUIRE(N <= 28000, "N too large for the device-side draws (<= 28000 poses per trajectory)");
     GSF_HIP(hipSetDevice(ctx->device));
     const size_t P = (size_t)B * (size_t)N, nb = (size_t)B, T = (size_t)(total_fixes > 0 ? total_fixes : 1);
@@ -137,7 +137,8 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     double* sp = sim3_pos ? sim3_pos : (double*)(w + o_sp); double* sq = (double*)(w + o_sq); int32_t* badq = (int32_t*)(w + o_bq);
     double* errs = (double*)(w + o_err);
     // ---- step 1 (GPS side of load_gps_data)
-    if ((rc = gsf_gps_rows_to_utm_batch_dev(ctx, gps_llh, gps_offsets, B, gps_utm, zone, south))) return rc;
+    // (gps_llh == NULL: the caller's gps_utm rows are the projected log already)
+    if (gps_llh && (rc = gsf_gps_rows_to_utm_batch_dev(ctx, gps_llh, gps_offsets, B, gps_utm, zone, south))) return rc;
     hipLaunchKernelGGL(run_compact_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, gps_t, (const double*)gps_utm, gps_offsets, ct, cp, rowmap, counts);
     GSF_HIP(hipGetLastError());
     if ((rc = launch_gps_prefilter_auto(ctx, ct, cp, gps_offsets, counts, B, max_fixes > 0 ? max_fixes : 1, &cfg->gps_filter, mt_state, ckeep, log_status, log_info))) return rc;

@@ -160,6 +160,9 @@ struct WaveArgs {
     int64_t B, N;
     const int64_t* offsets;                       // ragged batches: trajectory b = rows offsets[b]..offsets[b+1] (else b*N.., N rows)
     FitRows rows;                                 // which rows feed the pipeline's fit (gsf_set_sim3_rows)
+#ifdef GSF_EXP_HYBRID
+    int32_t use_pv;                               // exp/gsf_ekf_wave_hybrid.hip only (`make hybrid`): run-time choice of the variance source
+#endif
 };
 
 __device__ __forceinline__ int64_t uniform64(int64_t v)
@@ -970,7 +973,11 @@ __device__ __forceinline__ void wave_serial_chunks(const WaveArgs& a, const EkfC
 
         // ---- variances (ref :712-713, :723-731): scanned here, or -- PREVAR -- already computed by the helper wave (LDS)
         double Pf[3], Pm[3], kg[3];
+#ifdef GSF_EXP_HYBRID
+        if (PREVAR && (a).use_pv != 0) {
+#else
         if (PREVAR) {
+#endif
             const int64_t il = active ? i : N - 1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { Pf[c] = pv[(c * 3 + 0) * pv_stride + il]; Pm[c] = pv[(c * 3 + 1) * pv_stride + il]; kg[c] = pv[(c * 3 + 2) * pv_stride + il]; }

@@ -591,8 +591,7 @@ def benchmark_c1(slam, gps_t_raw, lat, lon, alt, repeats=20):
     'quaternions'} and its raw GNSS log (stamps, lat, lon, alt as load_gps_data reads them, ref :258).  Timed: the GPS leg of step 1
     (projection + sliding RANSAC pre-filter, ref :266-275), steps 2-5 (time alignment, row choice, robust Sim3, apply, EKF+RTS,
     ref :971-1010) and step 6 (error metric).  (bench.py feeds it the C1 shape -- BASELINE configs[0]: the 271-pose KITTI-04 track and
-    its 279 fixes from the committed fixtures; BASELINE.md has the reference's CPU figures: ~0.11 s for steps 2-5, 23-40 ms for the
-    pre-filter.)"""
+    its 279 fixes from the committed fixtures, and adds the reference's own CPU figures from profiles/rNN_reference_timing.json.)"""
     import time
     slam = {k: np.array(slam[k], dtype=np.float64) for k in ("timestamps", "positions", "quaternions")}
     ts, lats, lons, alts = (np.array(a, dtype=np.float64) for a in (gps_t_raw, lat, lon, alt))
@@ -628,7 +627,6 @@ def benchmark_c1(slam, gps_t_raw, lat, lon, alt, repeats=20):
     out["end_to_end_ms"] = {"best": sum(v["best"] for v in out.values()), "mean": sum(v["mean"] for v in out.values())}
     out["poses"] = int(len(slam["timestamps"]))
     out["gnss_fixes"] = int(len(ts))
-    out["reference_cpu_ms"] = {"steps_2_to_5": 110.0, "prefilter": "23-40", "source": "BASELINE.md (survey probe, 1 core)"}
     return out
 
 

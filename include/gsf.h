@@ -426,6 +426,8 @@ GSF_API int gsf_fuse_pipeline_robust_batch(gsf_ctx *ctx, const double *ts, const
    survive loader and pre-filter (what load_gps_data returns); aligned[B][N][3] / valid[B][N] = step 2's output; sim3_pos[B][N][3] (may be
    NULL) = step 4's positions; err_stats[3][B][4] = { count, mean, median, RMSE } of raw SLAM / Sim3 / EKF (:1027-1033);
    run_status[B] = GSF_RUN_* (a trajectory on which the reference raises has NaN outputs and its generator where the reference left it);
+   gps_llh == NULL: gps_utm is an INPUT -- the logs as load_gps_data's projection left them, (E, N, alt) per fix, NaN easting and northing
+   on a fix the loader drops -- and the chain starts at the pre-filter (zone / south are not written and may be NULL);
    inlier_mask[B][N] and trial_info[B][2] as in gsf_fuse_pipeline_robust_info_batch_dev (may be NULL). */
 GSF_API int gsf_run_fusion_batch_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, int64_t B, int64_t N,
                                      const double *gps_t, const double *gps_llh, const int64_t *gps_offsets, int64_t total_fixes,

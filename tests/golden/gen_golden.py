@@ -665,6 +665,14 @@ class HeadlessGui:
             rec["ekf_pos"], rec["ekf_quat"] = np.array(out[0]), np.array(out[1])
             return out
         ref.compute_sim3_transform_robust, ref.transform_trajectory, ref.apply_ekf_correction = robust, transform, ekf
+        # step 6 (ref :1027-1033): the distance matrices the reference's own loop forms for raw SLAM / Sim3 / EKF against the primary GPS, in its
+        # order; the printed mean / median / RMSE are :1033's expressions of their row minima (:1031)
+        orig_cdist = ref.distance.cdist
+        mats = []
+
+        def cdist_rec(a, b, *aa, **kk):
+            d = orig_cdist(a, b, *aa, **kk); mats.append(np.array(d)); return d
+        ref.distance.cdist = cdist_rec
         np.random.seed(seed)
         buf = io.StringIO()
         try:
@@ -673,8 +681,12 @@ class HeadlessGui:
             if ar.calls:
                 rec["aligned"], rec["valid"] = ar.calls[0]                   # step 2's alignment (ref :971)
         finally:
+            ref.distance.cdist = orig_cdist
             for k, v in saved.items():
                 setattr(ref, k, v)
+        if len(mats) >= 3:
+            e = [np.min(m, axis=1) for m in mats[:3]]                        # :1031
+            rec["step6"] = np.array([[len(x), np.mean(x), np.median(x), np.sqrt(np.mean(x ** 2))] for x in e])   # :1033
         rec["stdout"] = buf.getvalue()
         return rec
 
@@ -708,6 +720,11 @@ def _rows_case_adder(out, names, base, sec):
         if not fit_none:
             o.update(R=r["fit"][0], t=r["fit"][1], s=np.float64(r["fit"][2]), sim3_pos0=r["sim3_pos"][0], sim3_quat0=r["sim3_quat"][0],
                      ekf_pos=r["ekf_pos"], ekf_quat=r["ekf_quat"], ekf_aligned=r["ekf_aligned"], ekf_valid=r["ekf_valid"])
+            # step 6 against the primary GPS (rows raw SLAM / Sim3 / EKF x count, mean, median, RMSE); absent when no point lies past the first 5 s
+            o["step6"] = r.get("step6", np.full((3, 4), np.nan))
+            # the final state of np.random: where the run's draws (ref :405) left the global generator
+            st = np.random.get_state()
+            o["rng_end"] = np.concatenate([st[1].astype(np.uint32), np.array([st[2]], dtype=np.uint32)])
         for k, v in o.items():
             out[f"{name}_{k}"] = v
         names.append(name)

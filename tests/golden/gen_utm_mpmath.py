@@ -66,5 +66,35 @@ def main():
     print("wrote utm_mpmath.npz", len(pts), "points")
 
 
+def main_zones():
+    """Round 5: every one of the 60 zones, both hemispheres, latitudes from the equator to 84 N / 80 S, the central meridian, the zone
+    edges and points half a degree outside them (the reference picks ONE zone per log from the mean longitude, ref :131-133, so a log
+    that straddles an edge is projected partly off-zone) -> tests/golden/utm_zones_mpmath.npz.  Pins the forward series to the
+    definition and the INVERSE (direct Gaussian-latitude series) to the same points read backwards: a float64 (E, N) pair is within
+    1e-9 m of the exact image, i.e. within 1e-14 degree of the exact pre-image."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    lats = [1e-7, 0.5, 12.0, 30.0, 49.0336, 60.0, 72.0, 84.0, -0.5, -23.0, -45.0, -66.0, -80.0]
+    dlon = [0.0, 3.0, -3.0, 1.7, -2.2, 3.5, -3.5]
+    lat, lon, zone, south, e, n = [], [], [], [], [], []
+    k = 0
+    for z in range(1, 61):
+        lon0 = 6 * z - 183
+        for j in range(4):                                    # four points per zone, walking through both lists
+            la, dl = lats[k % len(lats)], dlon[(k // 2) % len(dlon)]
+            k += 1
+            lo = lon0 + dl
+            s_ = int(la < 0)
+            ee, nn = tm_exact(la, lo, z, s_)
+            lat.append(la); lon.append(lo); zone.append(z); south.append(s_); e.append(float(ee)); n.append(float(nn))
+    np.savez_compressed(os.path.join(here, "utm_zones_mpmath.npz"), lat=np.array(lat), lon=np.array(lon),
+                        zone=np.array(zone, np.int32), south=np.array(south, np.int32), E=np.array(e), N=np.array(n),
+                        meta=np.array(f"mpmath {mp.__version__} dps=50; definition-level TM; 60 zones x 4 points"))
+    print("wrote utm_zones_mpmath.npz", len(lat), "points")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "--zones" in sys.argv:
+        main_zones()
+    else:
+        main()

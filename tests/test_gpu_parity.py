@@ -175,6 +175,26 @@ def test_ekf_cases(E, orc, golden):
     assert worst < POS_GATE
 
 
+def test_utm_all_zones_vs_mpmath_definition(E, B, golden):
+    """K1 on the device, both directions, on the 240 points of all 60 zones (gen_utm_mpmath.py --zones: both hemispheres, zone edges, half
+    a degree outside them): forward within 5e-9 m of the 50-digit definition-level values, the inverse (direct Gaussian-latitude series,
+    round 5) within 1e-13 degree of the pre-image, round trip within 1e-9 m (easting) / 3e-9 m (northing) -- one batched call per direction, each point in its own zone."""
+    import torch
+    g = golden("utm_zones_mpmath.npz")
+    n = len(g["lat"])
+    dev = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+    offs = torch.arange(0, n + 1, dtype=torch.int64, device="cuda")
+    zone, south = dev(g["zone"], torch.int32), dev(g["south"], torch.int32)
+    e, nn, _, _ = B.utm_forward_batch(dev(g["lat"]), dev(g["lon"]), offs, zone, south)
+    assert (e.cpu().numpy() - g["E"]).__abs__().max() < 5e-9 and (nn.cpu().numpy() - g["N"]).__abs__().max() < 5e-9
+    la, lo = B.utm_inverse_batch(dev(g["E"]), dev(g["N"]), offs, zone, south)
+    dla, dlo = np.abs(la.cpu().numpy() - g["lat"]).max(), np.abs(lo.cpu().numpy() - g["lon"]).max()
+    assert dla < 1e-13 and dlo < 1e-13, (dla, dlo)
+    e2, n2, _, _ = B.utm_forward_batch(la, lo, offs, zone, south)
+    # (a latitude beyond 64 degrees is spaced 1.6e-9 m, a northing beyond 4.2e6 m up to 1.9e-9 m: eastings hold 1e-9 m, northings 3e-9 m)
+    assert np.abs(e2.cpu().numpy() - g["E"]).max() <= 1e-9 and np.abs(n2.cpu().numpy() - g["N"]).max() <= 3e-9
+
+
 def test_utm_vs_mpmath_definition(E, golden):
     g = golden("utm_mpmath.npz")
     for la, lo, z, s, Ee, Nn in zip(g["lat"], g["lon"], g["zone"], g["south"], g["E"], g["N"]):
