@@ -1115,7 +1115,7 @@ def robust_chain(torch, np, B, timed, dev, nb, N, fit_rows, parity=0):
                "deciding_trial_max_among_saturated": int(infoe[sat, 0].max().item()) if bool(sat.any()) else None,
                "draws_ms": ms_d, "draws_wall_us_per_trial_of_every_stream": ms_d * 1e3 / sc["max_trials"],
                "draws_wall_ns_per_stream_and_trial": ms_d * 1e6 / (nb * sc["max_trials"]),
-               "stages": "row choice -> compact -> early-exit probe (rounds of 1, 1, 2, 4, ... drawn-and-scored trials per trajectory) -> mt19937 choice + K2b for "
+               "stages": "row choice -> compact -> early-exit probe (rounds of 8 drawn-and-scored trials per trajectory) -> mt19937 choice + K2b for "
                          "the trials left of undecided trajectories -> Sim3(pose 0) -> K4"}
         if parity > 0:
             chain(); torch.cuda.synchronize()

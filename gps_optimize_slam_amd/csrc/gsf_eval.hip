@@ -88,11 +88,16 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
 // one-thread-per-query kernel's bit for bit; the sums of the mean / RMSE keep that kernel's order of partial sums only up to the
 // last digits (gate 1e-9 m in the tests).  271 poses: 111 -> ~25 us for one track, 139 -> ~60 us for 1 000.
 constexpr int EVAL_LDS_MAX_N = 1536;
-__global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const double* __restrict__ ts, const double* __restrict__ traj,
+// up to three trajectories per track against the SAME fixes in one launch (step 6 prints raw SLAM / Sim3 / EKF, ref :1027): blockIdx.y picks
+// the set; stats / errors of set k start at k * B * 4 / k * B * N
+struct EvalSets { const double* traj[3]; };
+__global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const double* __restrict__ ts, EvalSets sets,
                                                                        const double* __restrict__ gps, const uint8_t* __restrict__ valid,
                                                                        int64_t N, double skip, double* __restrict__ stats,
                                                                        double* __restrict__ errors)
 {
+    const double* __restrict__ traj = sets.traj[blockIdx.y];
+    stats += (int64_t)blockIdx.y * gridDim.x * 4; errors += (int64_t)blockIdx.y * gridDim.x * N;
     extern __shared__ double dynl[];                                     // cx[N], cy[N], cz[N], err[N], then int32 qidx[N]
     __shared__ double sh[EVAL_THREADS / 64];
     __shared__ double sh_med[2];
@@ -187,6 +192,28 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
 
 }  // namespace
 
+namespace gsf {
+// step 6 for the three tracks main_process_gui prints (raw SLAM, Sim3, EKF; ref :1027) against the same aligned fixes: ONE launch for tracks
+// up to EVAL_LDS_MAX_N poses; stats[3][B][4], errors[3][B][N]
+int launch_eval_errors3(gsf_ctx* ctx, const double* ts, const double* traj0, const double* traj1, const double* traj2, const double* aligned_gps,
+                        const uint8_t* valid, int64_t B, int64_t N, double skip_seconds, double* stats, double* errors)
+{
+    if (N <= EVAL_LDS_MAX_N) {
+        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B, 3), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, EvalSets{ { traj0, traj1, traj2 } },
+                           aligned_gps, valid, N, skip_seconds, stats, errors);
+        GSF_HIP(hipGetLastError());
+        return GSF_OK;
+    }
+    const double* tr[3] = { traj0, traj1, traj2 };
+    for (int k = 0; k < 3; ++k) {
+        hipLaunchKernelGGL(eval_errors_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), 0, ctx->stream, ts, tr[k], aligned_gps, valid, N, skip_seconds,
+                           stats + (size_t)k * (size_t)B * 4, errors + (size_t)k * (size_t)B * (size_t)N);
+        GSF_HIP(hipGetLastError());
+    }
+    return GSF_OK;
+}
+}  // namespace gsf
+
 extern "C" {
 
 int gsf_eval_errors_batch_dev(gsf_ctx* ctx, const double* ts, const double* traj_pos, const double* aligned_gps, const uint8_t* valid,
@@ -197,8 +224,8 @@ int gsf_eval_errors_batch_dev(gsf_ctx* ctx, const double* ts, const double* traj
     GSF_REQUIRE(ts && traj_pos && aligned_gps && valid && stats && errors, "NULL array");
     GSF_HIP(hipSetDevice(ctx->device));
     if (N <= EVAL_LDS_MAX_N)
-        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, traj_pos, aligned_gps, valid, N,
-                           skip_seconds, stats, errors);
+        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, EvalSets{ { traj_pos, nullptr, nullptr } },
+                           aligned_gps, valid, N, skip_seconds, stats, errors);
     else
         hipLaunchKernelGGL(eval_errors_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), 0, ctx->stream, ts, traj_pos, aligned_gps, valid, N, skip_seconds, stats, errors);
     GSF_HIP(hipGetLastError());

@@ -304,13 +304,16 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
 {
     __shared__ uint32_t mt[MT_N + 1];
     __shared__ uint32_t snap[MT_N + 1];
-    __shared__ int sh_nin[CH_MAX_TRIALS];
-    __shared__ double sh_score[CH_MAX_TRIALS];
-    __shared__ int32_t sh_end[CH_MAX_TRIALS];
     __shared__ PolyModel sh_model[64];                                    // models of the batch being scored (batches are 4, 8, 16, 32, then 64 trials)
-    extern __shared__ uint16_t dyn[];                                     // [jseq_elems] swap partners, then int32 idx[max_trials * ms]
-    uint16_t* jseq = dyn;
-    int32_t* sh_idx = (int32_t*)(dyn + ((jseq_elems + 1) & ~1));
+    // dynamic LDS, sized by max_trials (round 5: the per-trial arrays were static arrays of CH_MAX_TRIALS entries, 16 KB a block whatever the
+    // CONFIG's 50 trials, and with a 40 KB sampler buffer only TWO one-wave blocks fitted a CU -- 1 000 logs ran as two rounds):
+    // score[max_trials] (double), idx[max_trials * ms], end[max_trials], nin[max_trials] (int32), then the swap partners [jseq_elems] (uint16)
+    extern __shared__ double dyn[];
+    double* sh_score = dyn;
+    int32_t* sh_idx = (int32_t*)(sh_score + max_trials);
+    int32_t* sh_end = sh_idx + (size_t)max_trials * ms;
+    int* sh_nin = (int*)(sh_end + max_trials);
+    uint16_t* jseq = (uint16_t*)(sh_nin + max_trials);
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t r_base = offsets[b];
@@ -516,13 +519,19 @@ int gsf_ransac_poly_batch_dev(gsf_ctx* ctx, const double* t, const double* y, co
 
 // LDS of the chain kernel (40 KB dynamic next to 23 KB of static arrays): the sample sets of one window-axis, then the swap partners of as
 // many trials as the rest allows (at least one trial's worth)
-static int chain_lds(int32_t max_trials, int32_t min_samples, int32_t max_window_rows, int& jseq_elems, size_t& lds)
+static int chain_lds(int32_t max_trials, int32_t min_samples, int32_t max_window_rows, int64_t B, int& jseq_elems, size_t& lds)
 {
-    const size_t idx_bytes = (size_t)max_trials * (size_t)min_samples * 4;
-    if (idx_bytes + 2 * (size_t)max_window_rows + 4 > 40 * 1024) return 1;
-    int tb = (int)((40 * 1024 - idx_bytes - 4) / 2 / (size_t)max_window_rows); if (tb > 64) tb = 64;
+    // per trial: score 8 + end 4 + nin 4 + idx 4 * min_samples bytes; then the swap partners of as many buffered trials as the budget allows
+    // (at least one trial's worth).  Many logs: 16 buffered trials are enough for the batches scikit-learn's walk usually needs (4, 8, 16)
+    // and keep a block under 20 KB, i.e. every SIMD of a CU busy with its own log; few logs: up to 64 trials / 40 KB as before.
+    const size_t fixed = (size_t)max_trials * (16 + 4 * (size_t)min_samples);
+    const size_t budget = 56 * 1024;
+    if (fixed + 2 * (size_t)max_window_rows + 8 > budget) return 1;
+    int tb = (int)((budget - fixed - 8) / 2 / (size_t)max_window_rows);
+    const int cap = B > 256 ? 16 : 64;
+    if (tb > cap) tb = cap;
     jseq_elems = tb * max_window_rows;
-    lds = (size_t)((jseq_elems + 1) & ~1) * 2 + idx_bytes;
+    lds = fixed + (size_t)((jseq_elems + 3) & ~3) * 2;
     return 0;
 }
 
@@ -541,7 +550,7 @@ int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos
     GSF_REQUIRE(t && pos, "NULL rows");
     GSF_HIP(hipSetDevice(ctx->device));
     int jseq_elems = 0; size_t lds = 0;
-    GSF_REQUIRE(chain_lds(max_trials, min_samples, max_window_rows, jseq_elems, lds) == 0, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
+    GSF_REQUIRE(chain_lds(max_trials, min_samples, max_window_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, (const int32_t*)nullptr, win_rows, win_offsets,
                        (int)max_trials, (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status,
                        WinGen{ 0, min_samples, 0.0, 0.0, 1, 0 }, (int32_t*)nullptr);
@@ -562,7 +571,7 @@ int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, 
     GSF_REQUIRE(f->polynomial_degree >= 1 && f->polynomial_degree <= RP_MAX_DEGREE, "pre-filter polynomial degree must be in [1,3]");
     GSF_REQUIRE(max_log_rows >= 1 && max_log_rows <= 14000, "a log must hold 1 .. 14000 fixes for the device pre-filter");
     int jseq_elems = 0; size_t lds = 0;
-    GSF_REQUIRE(chain_lds(f->max_trials, f->min_samples, max_log_rows, jseq_elems, lds) == 0, "max_trials x min_samples / log length exceed the device sampler's LDS budget");
+    GSF_REQUIRE(chain_lds(f->max_trials, f->min_samples, max_log_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / log length exceed the device sampler's LDS budget");
     const WinGen gen{ f->use_sliding_window ? 1 : 2, f->min_samples, f->window_duration_seconds, f->window_duration_seconds * f->window_step_factor,
                       f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096 };
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, counts, (const int32_t*)nullptr,

@@ -109,6 +109,10 @@ int launch_ekf_block(gsf_ctx* ctx, bool pipeline, const double* ts, const double
 int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, const int64_t* offsets, const int32_t* counts, int64_t B,
                               int32_t max_log_rows, const gsf_prefilter_config* f, uint32_t* mt_state, uint8_t* keep, int32_t* log_status, int32_t* log_info);
 
+// step 6 for raw SLAM / Sim3 / EKF in one launch (gsf_eval.hip): stats[3][B][4], errors[3][B][N]
+int launch_eval_errors3(gsf_ctx* ctx, const double* ts, const double* traj0, const double* traj1, const double* traj2, const double* aligned_gps,
+                        const uint8_t* valid, int64_t B, int64_t N, double skip_seconds, double* stats, double* errors);
+
 // main_process_gui's row choice as a launch of its own (gsf_robust.hip: sim3_rows_kernel; ref :973-998): row_mask[B*N] / ragged, n_rows[B], status[B]
 int launch_sim3_rows(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
                      const FitRows& rule, uint8_t* row_mask, int32_t* n_rows, int32_t* status);

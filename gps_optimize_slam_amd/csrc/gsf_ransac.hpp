@@ -33,15 +33,21 @@ __device__ __forceinline__ int32_t fit_sample(const double* __restrict__ src, co
     return umeyama_finalize(H, ssq, sc, dc, n, R, t, s);
 }
 
-// squared residual of row r under (R, t, s): pure arithmetic, so that several rows' loads can be in flight together
+// squared residual of a row (x, y, z) -> (d0, d1, d2) under (R, t, s): pure arithmetic.  ONE definition behind the memory-reading form below
+// and the callers that hold their rows in registers (the early-exit probe), so that both form the same number.
+__device__ __forceinline__ double resid2_vals(const double x, const double y, const double z, const double d0, const double d1, const double d2,
+                                              const double* R, const double* t, double s)
+{
+    const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - d0;
+    const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - d1;
+    const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - d2;
+    return dx * dx + dy * dy + dz * dz;
+}
+// ... of row r of (src, dst): several rows' loads can be in flight together
 __device__ __forceinline__ double resid2(const double* __restrict__ src, const double* __restrict__ dst, int64_t r,
                                          const double* R, const double* t, double s)
 {
-    const double x = src[r * 3], y = src[r * 3 + 1], z = src[r * 3 + 2];
-    const double dx = s * (x * R[0] + y * R[1] + z * R[2]) + t[0] - dst[r * 3];
-    const double dy = s * (x * R[3] + y * R[4] + z * R[5]) + t[1] - dst[r * 3 + 1];
-    const double dz = s * (x * R[6] + y * R[7] + z * R[8]) + t[2] - dst[r * 3 + 2];
-    return dx * dx + dy * dy + dz * dz;
+    return resid2_vals(src[r * 3], src[r * 3 + 1], src[r * 3 + 2], dst[r * 3], dst[r * 3 + 1], dst[r * 3 + 2], R, t, s);
 }
 // ref :410-411 tests norm < thr, i.e. sqrt(d2) < thr.  The correctly rounded sqrt is only needed within a few ulp of the boundary:
 // d2 clearly below / above thr^2 decides without it (the band is ~50x wider than the rounding of d2 and thr^2).

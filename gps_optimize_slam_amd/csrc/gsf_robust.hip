@@ -116,14 +116,18 @@ __global__ __launch_bounds__(64) void compact_valid_kernel(const double* __restr
 // ---- exact early termination of the robust fit (gsf_set_option "ransac_early_exit") -------------------------------------------------
 // The reference's loop keeps a trial only if it counts STRICTLY more rows than the best so far (ref :413), so once a trial has counted all
 // n rows no later trial can change the inlier mask, the count, or the final fit: the rest of the max_trials draws only move the generator.
-// One wave per trajectory draws and scores its own trials in growing rounds (1, 1, 2, 4, ... <= 64 trials: a round costs one lane-parallel
-// 4-point fit whatever its size, a trial costs its draw -- ~2.3 us at 271 rows -- and one row-parallel count) and stops at the first trial
-// that counts every row.  A trajectory that is still undecided after `probe_trials` is handed to the wide kernels for the REST of its trials
+// One wave per trajectory draws and scores its own trials in rounds of PROBE_ROUND = 8 and stops after the round that holds the first trial
+// that counts every row.  Why 8: a round costs one lane-parallel 4-point fit whatever its size -- the Jacobi SVD of K2b's fit_sample, ~11 us
+// for a lone wave --, a trial its draw (~2.3 us at 271 rows) and one row-parallel count (~0.3 us), and the launch ends with its SLOWEST
+// trajectory.  Measured at 1 000 x 271 (rocprofv3, gpurun_out/r5e): rounds of 1, 1, 2, 4, 8 -- the kept trial is trial 0 on 75 % of the
+// tracks, within the first four on 99.3 %, at most trial 6 -- 79 us (four fits on the slowest track); rounds of 8 from the start: one fit.  A trajectory that is still undecided after `probe_trials` is handed to the wide kernels for the REST of its trials
 // (mt_choice_kernel + K2b from trial `drawn` on, the arg-max key carried over), so data that never saturates costs what it cost before.
 // Counts are formed with the functions K2b forms them with (gsf_ransac.hpp): the decision is the one the full chain takes.
 //   keys[b][2]      arg-max key of the trials scored here (0 = none usable), [1] = 0 (no caller-fed sample can be out of range)
 //   decided[b]      1 when a trial counted every row: R, t, s, mask, n_inliers are final; the generator stops after that trial's ROUND
 //   trial_info[b]   { deciding trial or -1, trials drawn here }
+constexpr int PROBE_ROUND = 8;
+constexpr int PROBE_TILE = 8;       // row iterations of a set held in registers by the probe (64 rows each)
 __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__ state, const double* __restrict__ src, const double* __restrict__ dst,
                                                           const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts, int max_trials,
                                                           int probe_trials, int ms, double thr, int32_t* sample_idx, int jseq_bytes,
@@ -144,8 +148,24 @@ __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__
         int pos = (int)st[MT_N];
         __syncthreads();
         const int limit = probe_trials < max_trials ? probe_trials : max_trials;
-        for (int round = 0; drawn < limit && !sat; ++round) {
-            int T = round < 2 ? 1 : (round < 8 ? (1 << (round - 1)) : 64);
+        // the rows of the set, held in registers when they fit (up to 64 x PROBE_TILE = 512 rows: lane l holds rows l, l + 64, ...): fetched once
+        // -- the loads travel while the first round is drawn -- instead of once per hypothesis (five dependent memory round trips per count
+        // were 4 us of a hypothesis's 5, gpurun_out/r5e)
+        const bool in_regs = n <= 64 * PROBE_TILE;
+        double rx[PROBE_TILE][6];
+#pragma unroll
+        for (int k = 0; k < PROBE_TILE; ++k) {
+            if (in_regs && k * 64 < n) {                                   // wave-uniform
+                const int64_t r = i0 + (k * 64 + lane < n ? k * 64 + lane : n - 1);
+                rx[k][0] = src[r * 3]; rx[k][1] = src[r * 3 + 1]; rx[k][2] = src[r * 3 + 2];
+                rx[k][3] = dst[r * 3]; rx[k][4] = dst[r * 3 + 1]; rx[k][5] = dst[r * 3 + 2];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) rx[k][c] = 0.0;
+            }
+        }
+        while (drawn < limit && !sat) {
+            int T = PROBE_ROUND;
             if (T > limit - drawn) T = limit - drawn;
             mt_draw_choice(mt, pos, n, T, ms, jseq, jseq_bytes / 2, my_idx + (size_t)drawn * ms, nullptr, lane);   // (ends on a block barrier: the sets are visible)
             double R[9], t[3], s = 0.0;
@@ -160,10 +180,20 @@ __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__
                 th[0] = lane_bcast(t[0], h); th[1] = lane_bcast(t[1], h); th[2] = lane_bcast(t[2], h);
                 const double sh = lane_bcast(s, h);
                 long long cnt = 0;
-                for (int r0 = 0; r0 < n; r0 += 64) {                       // ref :409-412
-                    const int r = r0 + lane;
-                    const bool in = r < n && is_inlier(src, dst, i0 + (r < n ? r : n - 1), Rh, th, sh, thr);
-                    cnt += __popcll(__ballot(in));
+                if (in_regs) {                                             // ref :409-412
+#pragma unroll
+                    for (int k = 0; k < PROBE_TILE; ++k) {
+                        if (k * 64 < n) {                                  // wave-uniform
+                            const bool in = (k * 64 + lane < n) && within(resid2_vals(rx[k][0], rx[k][1], rx[k][2], rx[k][3], rx[k][4], rx[k][5], Rh, th, sh), thr);
+                            cnt += __popcll(__ballot(in));
+                        }
+                    }
+                } else {
+                    for (int r0 = 0; r0 < n; r0 += 64) {
+                        const int r = r0 + lane;
+                        const bool in = r < n && is_inlier(src, dst, i0 + (r < n ? r : n - 1), Rh, th, sh, thr);
+                        cnt += __popcll(__ballot(in));
+                    }
                 }
                 if (cnt > best) { best = cnt; best_trial = drawn + h; }    // strict > keeps the first (:413)
                 if (cnt == (long long)n) { sat = true; break; }            // every row counted: nothing after this trial can be kept

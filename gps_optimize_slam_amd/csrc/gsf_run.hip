@@ -127,7 +127,7 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     auto take = [&](size_t bytes) { const size_t at = off; off = up256(off + bytes); return at; };
     const size_t o_ct = take(T * 8), o_cp = take(T * 24), o_map = take(T * 4), o_ck = take(T), o_cnt = take(nb * 4), o_ls = take(nb * 4), o_li = take(nb * 8),
                  o_fut = take(T * 24), o_so = take((nb + 1) * 8), o_as = take(nb * 4), o_sp = take(sim3_pos ? 0 : P * 24), o_sq = take(P * 32),
-                 o_bq = take(nb * 4), o_err = take(P * 8);
+                 o_bq = take(nb * 4), o_err = take(P * 24);
     int rc = ensure_run_scratch(ctx, off);
     if (rc) return rc;
     char* w = (char*)ctx->run_scratch;
@@ -160,9 +160,7 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     if (rc) return rc;
     // ---- step 4 for every pose, step 6
     if ((rc = gsf_apply_sim3_batch_dev(ctx, pos, quat, slam_off, B, R, t, s, sp, sq, badq))) return rc;
-    if ((rc = gsf_eval_errors_batch_dev(ctx, ts, pos, aligned, valid, B, N, cfg->eval_skip_seconds, err_stats, errs))) return rc;
-    if ((rc = gsf_eval_errors_batch_dev(ctx, ts, sp, aligned, valid, B, N, cfg->eval_skip_seconds, err_stats + nb * 4, errs))) return rc;
-    if ((rc = gsf_eval_errors_batch_dev(ctx, ts, pos_out, aligned, valid, B, N, cfg->eval_skip_seconds, err_stats + nb * 8, errs))) return rc;
+    if ((rc = launch_eval_errors3(ctx, ts, pos, sp, pos_out, aligned, valid, B, N, cfg->eval_skip_seconds, err_stats, errs))) return rc;
     hipLaunchKernelGGL(run_outcome_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, B, N, (const int32_t*)status, run_status, R, t, s, pos_out, quat_out,
                        sim3_pos, err_stats, n_inliers, (const int32_t*)badq);
     GSF_HIP(hipGetLastError());

@@ -199,7 +199,7 @@ def filter_gps_outliers_ransac(times, positions, config):
     ranges, wins = _prefilter_windows(times, config, need)
     longest = max((b - a for a, b in ranges), default=0) if ranges is not None else 0
     chain_ok = (ranges is not None and positions.shape[1] == 3 and longest <= 14000 and 1 <= trials <= 1024 and need <= 16 and 1 <= degree <= 3
-                and trials * need * 4 + 2 * longest + 4 <= 40 * 1024)    # gsf_gps_prefilter_chain's own limits (LDS budget of its sampler)
+                and trials * (16 + 4 * need) + 2 * longest + 8 <= 56 * 1024)    # gsf_gps_prefilter_chain's own limits (LDS budget of its sampler: chain_lds, csrc/gsf_gpsfilter.hip)
     if chain_ok:
         if not ranges:
             return times[:0], positions[:0]                              # no window had enough rows: nothing is ever marked (ref :199-236)

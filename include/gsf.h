@@ -170,8 +170,7 @@ GSF_API int gsf_trim(gsf_ctx *ctx);
                       ends where np.random ends after compute_sim3_transform_robust (EKFGPSSLAM.py:404-405) / 1: a trajectory stops at
                       the first trial that counts every row of its fit -- :413 keeps a trial only on a STRICTLY larger count, so no later
                       trial can change the mask, the count or the final fit; outputs identical bit for bit, GSF_SIM3_FLAG_SATURATED in the
-                      status word, the generator left after the round of trials that held the deciding one (rounds of 1, 1, 2, 4, ...
-                      <= 64 trials).  Trajectories that never saturate (one GNSS outlier beyond the threshold is enough) run all
+                      status word, the generator left after the round of eight trials that held the deciding one.  Trajectories that never saturate (one GNSS outlier beyond the threshold is enough) run all
                       max_trials as before.  The Python batch binding switches it ON, the single-track drop-in never uses it
      "ransac_probe_trials"  (default 64) how many trials the early-exit probe draws and scores per trajectory (one wave each) before
                       the wide kernels take the rest of an undecided trajectory's trials

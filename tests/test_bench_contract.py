@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed sample line (profiles/r04_bench_default_under_rocprof.json: the default
+"""The bench.py output contract, checked on the committed sample line (profiles/rNN_bench_default_under_rocprof.json of the latest round: the default
 `python bench.py` run of make_profiles.sh on an MI355X) and on bench.py's own constants and helpers -- CPU tier, no GPU needed."""
 import ast
 import json
@@ -7,8 +7,14 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def latest_tag():
+    """rNN of the newest committed profile set (profiles/rNN_bench_default_under_rocprof.json)"""
+    import glob
+    return os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default_under_rocprof.json")))[-1]).split("_")[0]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r04_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", f"{latest_tag()}_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -40,6 +46,10 @@ def test_committed_bench_line_has_the_contract_fields():
     e = d["extra"]
     assert e["pcie_inclusive"]["poses_per_s"] < d["value"] and e["c1_drop_in"]["end_to_end_ms"]["best"] > 0
     assert e["robust_chain_c2"]["ms"] > 0 and e["geodetic_chain_c2"]["ms"] > 0
+    if "all_trials" in e["robust_chain_c2"]:             # round 5: the exact early exit next to the chain that draws every trial, and the whole-run chain
+        rc = e["robust_chain_c2"]
+        assert rc["outputs_identical_in_both_modes"] is True and rc["ms"] < rc["all_trials"]["ms"] and 0.0 <= rc["saturated_share"] <= 1.0
+        assert e["full_chain_c2"]["ms"] > 0 and e["full_chain_c2"]["run_status_nonzero"] == 0
 
 
 def test_committed_traffic_profile_matches_the_kernel_sources():
@@ -47,10 +57,10 @@ def test_committed_traffic_profile_matches_the_kernel_sources():
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+    doc = json.load(open(os.path.join(ROOT, "profiles", f"{latest_tag()}_traffic.json")))
     assert doc["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/make_profiles.sh + tools/collect_profiles.py after changing a kernel"
     got, src = bench.profiled_traffic("c2", "ekf_wave_kernel<true, true, 1>", 64000)
-    assert src == "r04_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
+    assert src == f"{latest_tag()}_traffic.json" and 0.9 * 39295000 < got < 1.3 * 39295000      # C2: counters ~ algorithmic bytes (nothing re-read from HBM)
     v = bench.profiled_issue("c2", "ekf_wave_kernel<true, true, 1>", 64000, 0.018)
     assert v is not None and 4.0e6 < v["valu_wave_instructions_per_launch"] < 6.0e6 and 0.3 < v["frac"] < 0.6
 
@@ -143,5 +153,5 @@ def test_design_document_quotes_the_committed_profiles():
     import subprocess
     import sys
     for tool in ("design_table.py", "design_chains.py"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "r04", "--check"], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), latest_tag(), "--check"], capture_output=True, text=True)
         assert r.returncode == 0, (tool, r.stdout[-300:], r.stderr[-300:])

@@ -693,13 +693,21 @@ def test_time_alignment_long_track_global_staging(E, orc):
     np.testing.assert_allclose(al[va], alo[va], atol=5e-8, rtol=0)
 
 
-def test_c3_full_size_properties(B):
-    """BASELINE config C3 at FULL size (100 000 x 1 000 poses, 14.5 GB): size-independent properties of the fused batch."""
+def test_c3_full_size_properties(B, orc):
+    """BASELINE config C3 at FULL size (100 000 x 1 000 poses, 14.5 GB): size-independent properties of the fused batch, and a sample of
+    48 trajectories spread over it (first / middle / last slice) against the oracle on the same inputs."""
     import torch
     nb, N = 100_000, 1000
     batch = B.TrajectoryBatch.synthetic(nb, N, layout=0, seed=20250523)
     out, R, t, s = B.fuse_pipeline_batch(batch)
     torch.cuda.synchronize()
+    idx = np.concatenate([np.arange(16), nb // 2 + np.arange(16), nb - 16 + np.arange(16)])
+    ix = torch.as_tensor(idx, device="cuda")
+    hh = {k: getattr(batch, k).index_select(0, ix).cpu().numpy() for k in ("ts", "pos", "quat", "gps", "valid")}
+    po, qo, sto, Ro, _, so = orc.fuse_pipeline_batch(hh["ts"], hh["pos"], hh["quat"], hh["gps"], hh["valid"])
+    pg, qg, sg = out.pos.index_select(0, ix).cpu().numpy(), out.quat.index_select(0, ix).cpu().numpy(), out.status.index_select(0, ix).cpu().numpy()
+    assert np.abs(pg - po).max() < POS_TOL and np.abs(qg - qo).max() < Q_TOL and ((sg & ~(16 << 8)) == sto).all()
+    assert np.abs(R.index_select(0, ix).cpu().numpy() - Ro).max() < 2e-9 and np.abs(s.index_select(0, ix).cpu().numpy() - so).max() < 1e-11
     assert torch.isfinite(out.pos).all() and torch.isfinite(out.quat).all() and torch.isfinite(s).all()
     assert ((out.quat.pow(2).sum(dim=2) - 1).abs().max().item()) < 1e-12                 # unit quaternions
     assert (s - 1.0).abs().max().item() < 0.12                                            # planted scales are U(0.9, 1.1)

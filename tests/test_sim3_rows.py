@@ -252,11 +252,11 @@ def test_robust_chain_on_stacked_copies_equals_main_process_gui(B, golden):
         else:
             nrows, trials = len(g[f"{n}_sim3_idx"]), cfg["sim3_ransac"]["max_trials"]
             # saturated <=> the kept trial counted every row AND lies inside the probe's 64 trials; such a track drew the probe's rounds up
-            # to the one holding that trial (1, 1, 2, 4, ... trials), every other track all max_trials
+            # to the one holding that trial (rounds of eight), every other track all max_trials
             expect = (nin == nrows) & (info[:, 0] >= 0) & (info[:, 0] < 64)
             assert torch.equal(sat, expect), n
             d = info_e[:, 0].cpu().numpy()
-            round_end = np.array([1 if k < 1 else 2 if k < 2 else 2 ** (int(np.floor(np.log2(k))) + 1) for k in np.maximum(d, 0)])
+            round_end = np.array([(k // 8 + 1) * 8 for k in np.maximum(d, 0)])
             drawn = torch.as_tensor(np.where(sat.cpu().numpy(), np.minimum(round_end, min(64, trials)), trials), dtype=torch.int32, device="cuda")
             assert torch.equal(info_e[:, 1], drawn) and (info[:, 1] == trials).all(), (n, info_e[:, 1].tolist(), drawn.tolist())
         p, q, status = out.host_traj_major()

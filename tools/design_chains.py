@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
-"""Rewrites the "Chains and host-level figures" paragraph of DESIGN.md section 5 from the committed bench line (profiles/rNN_bench_default_under_rocprof.json),
-so that the prose quotes what the committed line holds.  usage: python tools/design_chains.py [r04] [--check]"""
+"""Rewrites the "Chains and host-level figures" block of DESIGN.md section 5 (between the CHAINS markers) from the committed bench line
+(profiles/rNN_bench_default_under_rocprof.json), so that the prose quotes what the committed line holds.
+usage: python tools/design_chains.py [r05] [--check]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
+BEGIN, END = "<!-- BEGIN CHAINS (tools/design_chains.py) -->", "<!-- END CHAINS -->"
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
 d = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_default_under_rocprof.json")).read().strip().splitlines()[-1]); e = d["extra"]
-r, r8, c, c5 = e["robust_chain_c2"], e["robust_chain_8192"], e["c1_drop_in"], e["c5_shard_1gpu"]
+r, r8, c, c5, fc = e["robust_chain_c2"], e["robust_chain_8192"], e["c1_drop_in"], e["c5_shard_1gpu"], e["full_chain_c2"]
 hp = e.get("host_pointer_entry", {})
-new = f"""Chains and host-level figures of the same bench line (`profiles/{tag}_bench_default_under_rocprof.json`, `extra` block; wall-clock of the
-whole chain, not one kernel; all with the reference's Sim3 rows): robust chain 1 000 × 271 (row choice → compaction → draw → K2b → Sim3 → K4) {r['ms']:.2f} ms (draws {r['draws_ms']:.2f} + K2b 0.29)
-and {r8['ms']:.1f} ms for 8 192 streams ({r8['ms_per_1000_streams']:.2f} ms per 1 000 streams: {r8['per_stream_cost_vs_1000_streams']:.3f} of the 1 000-stream cost per stream, the draws at {r8['draws_ns_per_stream_trial']:.2f} ns per stream-trial either way);
-chain from the geodetic log (K1 → align → pipeline) {e['geodetic_chain_c2']['ms']:.3f} ms; C2 in the time-major layout (two fused transposes + pipeline) {e['c2_time_major_pipeline_ms']:.3f} ms; C1 drop-in (271 poses, warm, under the
-profiler) GPS leg {c['gps_projection_and_prefilter_ms']['best']:.2f} ms + steps 2–5 {c['steps_2_to_5_ms']['best']:.2f} ms + metric {c['step_6_error_metric_ms']['best']:.2f} ms = **{c['end_to_end_ms']['best']:.2f} ms** end to end (reference ≈ 130–150 ms); C5 shard on one GPU
-{c5['traj_major_wave_per_traj']['pass_ms']:.1f} ms per pass trajectory-major ({c5['traj_major_wave_per_traj']['hbm_frac']:.3f} of peak) vs {c5['time_major_lane_per_traj']['pass_ms']:.1f} ms time-major ({c5['time_major_lane_per_traj']['hbm_frac']:.3f}; 54.6 ms in round 3, fitting every valid row);
-the host-pointer entry of the boundary (host arrays in and out, PCIe included) {hp.get('ms_per_call', float('nan')):.2f} ms per C2 call = {hp.get('poses_per_s', float('nan')) / 1e9:.2f} G poses/s (the torch-side
-`pcie_inclusive` loop of the same line reads {e['pcie_inclusive']['ms_per_step']:.1f} ms under rocprofv3, which slows the copies; 0.8–1.1 ms without it).
-"""
+hist = ", ".join(f"{v} after {k}" for k, v in r["trials_drawn_by_saturated_trajectories_histogram"].items())
+sp = fc["stage_split"]
+rf = c.get("reference_cpu_ms", {})
+new = f"""{BEGIN}
+* **Headline** (`value`): C2 1 000 × 271, fused pipeline on the reference's Sim3 rows, {d['steps']} graph-replayed steps: {d['ms_per_step'] * 1e3:.2f} µs per step =
+  {d['value'] / 1e9:.2f} G fused poses/s; kernel {d['roofline']['kernel_ms'] * 1e3:.2f} µs, {d['roofline']['frac']:.3f} of HBM peak on the algorithmic 145 B/pose (bound: `{d['roofline']['bound']}`); gate on the timed outputs:
+  ATE RMSE {d['ate_rmse_vs_cpu_ref_m']:.1e} m, max |Δp| {d['max_abs_pos_err_m']:.1e} m vs the oracle, status words equal.  CPU beside it: the oracle (C port) {d['cpu_baseline']['value'] / 1e6:.2f} M poses/s on one core,
+  {d['cpu_baseline']['all_cores']['value'] / 1e6:.1f} M on {d['cpu_baseline']['all_cores']['cores']}; the reference's own Python {d['cpu_baseline']['reference_python'].get('reference_python_poses_per_s', float('nan')) / 1e3:.1f} k poses/s.
+* **Robust chain 1 000 × 271** (row choice → compaction → probe → K2b → Sim3 of pose 0 → K4): **{r['ms']:.3f} ms** with the exact early exit ({r['poses_per_s'] / 1e9:.2f} G poses/s) against
+  {r['all_trials']['ms']:.2f} ms drawing all 1 000 trials ({r['speedup_over_all_trials']:.1f}×); every output word identical in both modes: {r['outputs_identical_in_both_modes']}; {r['saturated_trajectories']} of {r['streams']} trajectories
+  saturated (trials drawn: {hist}; the kept trial is at most trial {r['deciding_trial_max_among_saturated']}); 8 192 streams: {r8['ms']:.3f} ms / {r8['all_trials']['ms']:.1f} ms.  The draws alone for 1 000 × 1 000 trials: {r['draws_ms']:.2f} ms
+  ({r['draws_wall_us_per_trial_of_every_stream']:.2f} µs of wall time per trial with every stream drawing in parallel = {r['draws_wall_ns_per_stream_and_trial']:.2f} ns per stream and trial).
+* **Steps 1–6 as one chain, 1 000 × 271** (`full_chain_c2`, {fc['gnss_fixes']:,} fixes): **{fc['ms']:.2f} ms** = {fc['poses_per_s'] / 1e6:.0f} M poses/s with the early exit, {fc['all_trials_ms']:.2f} ms without; stages on their own:
+  geodesy slice {sp['geodesy_slice_ms'] * 1e3:.0f} µs, pre-filter {sp['prefilter_ms'] * 1e3:.0f} µs, alignment {sp['time_alignment_ms'] * 1e3:.0f} µs, robust steps 3–5 {sp['robust_steps_3_to_5_ms'] * 1e3:.0f} µs, apply {sp['apply_sim3_all_poses_ms'] * 1e3:.0f} µs, metric of three tracks
+  {sp['error_metric_3_tracks_ms'] * 1e3:.0f} µs; step-6 RMSE (mean over the batch) Sim3 {fc['step6_rmse_m_mean']['sim3']:.2f} m → EKF {fc['step6_rmse_m_mean']['ekf']:.2f} m.  The reference's Python takes ≈ {rf.get('steps_2_to_5', float('nan')):.0f} ms for steps 2–5 of ONE such track.
+* Chain from the geodetic log with the plain fit (K1 → align → pipeline) {e['geodetic_chain_c2']['ms'] * 1e3:.0f} µs; C2 in the time-major layout (two fused transposes + pipeline) {e['c2_time_major_pipeline_ms'] * 1e3:.0f} µs.
+* **C1 drop-in** (271 poses, warm): GPS leg {c['gps_projection_and_prefilter_ms']['best']:.2f} ms + steps 2–5 {c['steps_2_to_5_ms']['best']:.2f} ms + metric {c['step_6_error_metric_ms']['best']:.2f} ms = **{c['end_to_end_ms']['best']:.2f} ms** end to end; the reference itself:
+  steps 2–5 {rf.get('steps_2_to_5', float('nan')):.0f} ms, of it the robust fit {rf.get('compute_sim3_transform_robust', float('nan')):.0f} ms, `apply_ekf_correction` {rf.get('apply_ekf_correction', float('nan')):.0f} ms ({rf.get('source', '?')}).
+* **C5 shard on one GPU** ({c5['trajectories']:,} × 1 000): {c5['traj_major_wave_per_traj']['pass_ms']:.1f} ms per pass trajectory-major ({c5['traj_major_wave_per_traj']['hbm_frac']:.3f} of peak; gate vs the oracle on {c5['traj_major_wave_per_traj'].get('gate_vs_oracle', {}).get('trajectories', '?')} trajectories of three chunks: max |Δp|
+  {c5['traj_major_wave_per_traj'].get('gate_vs_oracle', {}).get('max_abs_pos_err_m', float('nan')):.1e} m) vs {c5['time_major_lane_per_traj']['pass_ms']:.1f} ms time-major ({c5['time_major_lane_per_traj']['hbm_frac']:.3f}).
+* Host-pointer entry of the boundary (host arrays in and out, PCIe included) {hp.get('ms_per_call', float('nan')):.2f} ms per C2 call = {hp.get('poses_per_s', float('nan')) / 1e9:.2f} G poses/s — never `value`; torch-side `pcie_inclusive` {e['pcie_inclusive']['ms_per_step']:.2f} ms under rocprofv3.
+{END}"""
 p = os.path.join(ROOT, "DESIGN.md"); s = open(p).read()
-i = s.index("Chains and host-level figures of the same bench line"); j = s.index("Box to box these figures move")
+i, j = s.index(BEGIN), s.index(END) + len(END)
 if "--check" in sys.argv:
     sys.exit(0 if s[i:j] == new else 1)
 open(p, "w").write(s[:i] + new + s[j:])

@@ -4,7 +4,7 @@ rocprofv3's average duration of that kernel at that grid in the kernel trace of 
 tools/bench_kernels.py for the auxiliary kernels), traffic = the PMC passes collected in rNN_traffic.json.  The table between the
 markers in DESIGN.md is REPLACED, so the document cannot quote a number the profiles do not hold.
 
-usage: python tools/design_table.py [r04] [--check]     (--check: exit 1 if DESIGN.md is not up to date)"""
+usage: python tools/design_table.py [r05] [--check]     (--check: exit 1 if DESIGN.md is not up to date)"""
 import csv
 import json
 import os
@@ -25,6 +25,9 @@ ROWS = [
     ("bench_default", "ekf_fuse_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "windows_fused_kernel", 1000064, "C4 1 M windows x 50 pairs (Umeyama)", 1_000_000, 1_000_000 * 2504, "windows"),
     ("bench_default", "sim3_rows_kernel", 64000, "row choice (ref :973-998) on its own: first stage of the robust chain, 1 000 x 271", 271_000, None, "rows"),
+    ("bench_default", "robust_probe_kernel", 64000, "early-exit probe of the robust chain, 1 000 x 271: draws + scores its own trials until one counts every row (ref :413)", 1000, None, "trajectories"),
+    ("bench_default", "gps_prefilter_chain_kernel", 64000, "GPS pre-filter of 1 000 logs (whole-run chain), windows walked on the device", 261_564, None, "fixes"),
+    ("bench_default", "eval_errors_lds_kernel", 768000, "error metric of raw SLAM / Sim3 / EKF in one launch (whole-run chain), 1 000 x 271", 813_000, None, "poses"),
     ("aux", "apply_sim3_slab_kernel", 25600000, "K3 apply Sim3, 1e8 poses", 100_000_000, 100_000_000 * 112, "poses"),
     ("aux", "utm_kernel<false>", 25600000, "K1 UTM forward, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
     ("aux", "utm_kernel<true>", 25600000, "K1 UTM inverse, 1e8 points", 100_000_000, 100_000_000 * 32, "points"),
@@ -90,7 +93,7 @@ def table(tag):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r04"
+    tag = args[0] if args else "r05"
     path = os.path.join(ROOT, "DESIGN.md")
     doc = open(path).read()
     if BEGIN not in doc or END not in doc:
