@@ -124,6 +124,7 @@ SIGNATURES = {
     "gsf_gps_prefilter_chain": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "gsf_gps_prefilter_auto_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.POINTER(PrefilterConfig), _vp, _vp, _vp, _vp]),
     "gsf_run_fusion_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, C.POINTER(RunConfig), _vp] + [_vp] * 18),
+    "gsf_run_fusion_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, C.POINTER(RunConfig), _vp] + [_vp] * 18),
     "gsf_sim3_umeyama_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_windows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsf_sim3_umeyama_windows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

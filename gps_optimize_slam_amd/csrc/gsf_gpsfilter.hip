@@ -94,10 +94,101 @@ __device__ __forceinline__ PolyModelT<MAXD> fit_subset_t(const double* __restric
     m.intercept = ymean - off;
     return m;
 }
+// The same fit with every array in REGISTERS: fit_subset_t's c[MAXD][MAXS] / yy[MAXS] are indexed by run-time loop bounds (ms, degree), which
+// puts them in scratch memory -- 656 bytes per lane in the chain kernel, and the two fits of a window-axis problem (the batch's models, the
+// winner's model again) were 51 % of its time (23 k + 27 k of 98 k cycles, in-kernel clocks, gpurun_out/r5h/pf_timing.log).  Here every loop
+// has a compile-time bound and is unrolled; rows >= ms and columns >= degree hold zeros, which the sums take in as exact no-ops (x + 0 * 0 = x),
+// so the operations that matter happen in fit_subset_t's order: the same bits.
+template <int MAXD, int MAXS>
+__device__ __forceinline__ PolyModelT<MAXD> fit_subset_regs(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
+                                                            const int ms, const int degree, const int ystride)
+{
+    double c[MAXD][MAXS], yy[MAXS], mean[MAXD], ymean = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) mean[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const bool on = i < ms;
+        const int32_t ix = idx[on ? i : 0];
+        const double ti = t[ix], yv = y[(int64_t)ix * ystride];
+        double tk = ti;
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) {
+            const bool use = on && k < degree;
+            c[k][i] = use ? tk : 0.0;
+            mean[k] += use ? tk : 0.0;
+            tk *= ti;
+        }
+        yy[i] = on ? yv : 0.0; ymean += on ? yv : 0.0;
+    }
+    const double rn = 1.0 / (double)ms;
+    ymean *= rn;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) mean[k] *= rn;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const bool on = i < ms;
+        yy[i] = on ? yy[i] - ymean : 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) c[k][i] = (on && k < degree) ? c[k][i] - mean[k] : 0.0;
+    }
+    double Rm[MAXD][MAXD], z[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+        z[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXD; ++j) Rm[k][j] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+        if (k < degree) {                                                 // (uniform over the wave: degree is a launch parameter)
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                double d = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAXS; ++i) d += c[j][i] * c[k][i];
+                Rm[j][k] = d;
+#pragma unroll
+                for (int i = 0; i < MAXS; ++i) c[k][i] -= d * c[j][i];
+            }
+            double nn = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) nn += c[k][i] * c[k][i];
+            nn = sqrt(nn);
+            Rm[k][k] = nn;
+            const double inv = nn > 0.0 ? 1.0 / nn : 0.0;
+            double d = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) { c[k][i] *= inv; d += c[k][i] * yy[i]; }
+            z[k] = d;
+        }
+    }
+    PolyModelT<MAXD> m;
+#pragma unroll
+    for (int k = MAXD - 1; k >= 0; --k) {
+        double v = z[k];
+#pragma unroll
+        for (int j = k + 1; j < MAXD; ++j) if (j < degree) v -= Rm[k][j] * m.coef[j];
+        m.coef[k] = (k < degree && Rm[k][k] > 0.0) ? v / Rm[k][k] : 0.0;
+    }
+    double off = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) if (k < degree) off += mean[k] * m.coef[k];
+    m.intercept = ymean - off;
+    return m;
+}
+// REGS: the register form -- for the chain kernel, one wave per SIMD with registers to spare; the thread-per-trial kernels of the fed-sample
+// route run several waves per SIMD and keep the compact scratch form (90 instead of 216 registers) unless GSF_POLY_FIT_REGS says otherwise
+#ifndef GSF_POLY_FIT_REGS
+#define GSF_POLY_FIT_REGS 0
+#endif
+template <bool REGS = (GSF_POLY_FIT_REGS != 0)>
 __device__ __forceinline__ PolyModel fit_subset(const double* __restrict__ t, const double* __restrict__ y, const int32_t* __restrict__ idx,
                                                 int ms, int degree, int ystride = 1)
 {
-    return fit_subset_t<RP_MAX_DEGREE, RP_MAX_SAMPLES, false>(t, y, idx, ms, degree, ystride);
+    if (!REGS) return fit_subset_t<RP_MAX_DEGREE, RP_MAX_SAMPLES, false>(t, y, idx, ms, degree, ystride);
+    if (ms <= 8) return fit_subset_regs<RP_MAX_DEGREE, 8>(t, y, idx, ms, degree, ystride);
+    return fit_subset_regs<RP_MAX_DEGREE, RP_MAX_SAMPLES>(t, y, idx, ms, degree, ystride);
 }
 
 // sklearn.linear_model._ransac._dynamic_max_trials
@@ -288,6 +379,17 @@ __device__ __forceinline__ void score_trial(const double* __restrict__ tp, const
 // either AND the axis mask into the window mask or -- no consensus set: the reference's exception -- drop the window and skip its
 // remaining axes (they consume nothing).  keep[] = OR over the successful windows.  One wave per log.
 constexpr int CH_MAX_TRIALS = 1024;
+constexpr int PF_TILE = 8;            // row iterations of a window held in registers by the chain kernel (64 rows each)
+#ifdef GSF_PF_TIMING
+// diagnostic build only (make pf_timing, tools/experiments/prefilter_timing.py): shader-clock totals per phase of the chain, written by lane 0 into
+// log_info[b * 16 + k] (the caller passes 16 ints per log): 0 snapshot, 1 draw, 2 fit, 3 score, 4 walk, 5 rewind, 6 final model + mask, 7 fold,
+// 8 window search, 9 problems, 10 whole kernel
+#define PF_T0() long long pf_t_ = clock64()
+#define PF_ADD(k) do { const long long n_ = clock64(); pf_acc[k] += n_ - pf_t_; pf_t_ = n_; } while (0)
+#else
+#define PF_T0() do { } while (0)
+#define PF_ADD(k) do { } while (0)
+#endif
 // Where the windows of a log come from.  mode 0: the caller lists them (win_rows / win_offsets: the host walked the stamps).  mode 1: the
 // kernel walks the stamps itself the way the reference does (ref :199-234: windows [w0, w0 + width) advanced by `stride`, one extra tail
 // window ending just past the last stamp; a window with fewer than `need` rows is skipped) -- sorted stamps only, so that every window is
@@ -316,6 +418,10 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     uint16_t* jseq = (uint16_t*)(sh_nin + max_trials);
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
+#ifdef GSF_PF_TIMING
+    long long pf_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const long long pf_start = clock64();
+#endif
     const int64_t r_base = offsets[b];
     const int n_log = counts ? counts[b] : (int)(offsets[b + 1] - r_base);   // (counts: logs in fixed-stride slots, e.g. after the loader's rows were compacted)
     uint32_t* st = state + b * MT_STATE_WORDS;
@@ -334,33 +440,54 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
         const int n = r1 - r0;
         int wstat = 0;
         if (n < ms || r0 < 0 || r1 > n_log) return 2;                     // ref :209: too few rows, window not processed
-        // scikit-learn's sampler takes the permutation route only for 0.01 < k/n < 0.99; other ratios (tracking selection / reservoir
-        // sampling) are not restated on the device: the log is flagged and left to the host-drawn path
+        // scikit-learn's sampler takes the permutation route only for 0.01 < k/n < 0.99.  Above that range it samples by reservoir: rows
+        // 0 .. k-1, then one randint per FURTHER row -- and with min_samples <= 16 a ratio >= 0.99 means n == k: no further row, no draw,
+        // every trial's sample is rows 0 .. k-1 (a window of exactly min_samples fixes: the tail of a log, a thinned log).  Below the range
+        // (tracking selection, n > 100 k) the log is flagged and left to the host-drawn path.
         const double ratio = (double)ms / (double)n;
-        if (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems) { lstat = 2; return 3; }
+        const bool identity = n == ms;
+        if (!identity && (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems)) { lstat = 2; return 3; }
         const double* tp = t + r_base + r0;
         // window mask lives in keep[] itself as bit 1 (AND over axes), folded into bit 0 (OR over windows) when the window succeeds
         for (int i = lane; i < n; i += 64) keep[r_base + r0 + i] |= 2;
+        // the window's rows in registers when they fit (up to 64 x PF_TILE = 512 rows; lane l holds rows l, l + 64, ...): the stamps once per
+        // window, an axis's values once per axis -- every trial's two scoring passes and the final mask read them from there instead of memory
+        const bool in_regs = n <= 64 * PF_TILE;
+        double tv[PF_TILE], yv[PF_TILE];
+#pragma unroll
+        for (int k = 0; k < PF_TILE; ++k) { const int i = k * 64 + lane; tv[k] = (in_regs && k * 64 < n) ? tp[i < n ? i : n - 1] : 0.0; yv[k] = 0.0; }
         for (int ax = 0; ax < 3 && wstat == 0; ++ax) {
             const double* yp = pos + (r_base + r0) * 3 + ax;
+#pragma unroll
+            for (int k = 0; k < PF_TILE; ++k) { const int i = k * 64 + lane; if (in_regs && k * 64 < n) yv[k] = yp[(int64_t)(i < n ? i : n - 1) * 3]; }
+            PF_T0();
             for (int i = lane; i <= MT_N; i += 64) snap[i] = (i < MT_N) ? mt[i] : (uint32_t)pos_mt;
             __syncthreads();
+            PF_ADD(0);
             // RANSACRegressor.fit's loop over the trials, in order, with the trials drawn and scored in growing batches (8, 16, 32, ...):
             // the loop shortens max_trials as soon as a consensus set is found (typically to 4-15 of the 50), and every trial costs
             // ~600 dependent instructions of the stream walk.  The walk itself runs redundantly on every lane (wave-uniform state).
-            int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0;
+            int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0, last_nb = 0;
             double best_score = -INFINITY, max_tr = (double)max_trials;
             for (int tbn = 4; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
                 const int nb = (max_trials - drawn < tbn) ? (max_trials - drawn) : tbn;
                 if (nb <= 0) break;
-                mt_draw_choice(mt, pos_mt, n, nb, ms, jseq, jseq_elems, sh_idx + (size_t)drawn * ms, sh_end + drawn, lane);
+                if (identity) {
+                    for (int e = lane; e < nb * ms; e += 64) sh_idx[(size_t)drawn * ms + e] = e % ms;
+                    for (int tau = lane; tau < nb; tau += 64) sh_end[drawn + tau] = 0;      // nothing consumed
+                    __syncthreads();
+                } else {
+                    mt_draw_choice(mt, pos_mt, n, nb, ms, jseq, jseq_elems, sh_idx + (size_t)drawn * ms, sh_end + drawn, lane);
+                }
+                PF_ADD(1);
                 // models: a lane per trial (at most 32 of them work); scores: the whole wave over the ROWS of one trial at a time -- a batch
                 // is 4-64 trials of ~150 rows, and a lane walking all rows of its trial alone was 44 of a window-axis's 85 us
                 for (int tau = lane; tau < nb; tau += 64) {
-                    sh_model[tau] = fit_subset(tp, yp, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, 3);
+                    sh_model[tau] = fit_subset<true>(tp, yp, sh_idx + (size_t)(drawn + tau) * ms, ms, degree, 3);
                     sh_end[drawn + tau] += raw_base;                          // outputs consumed since the window-axis start
                 }
                 __syncthreads();
+                PF_ADD(2);
                 // (the R^2 score below is summed per lane and then across the wave; score_trial / ransac_poly_kernel of the fed-sample route
                 // sum row after row on one thread.  Equal inlier counts are ordered by the score with an exact compare, so a near-tie in the
                 // last ulp may resolve differently on the two routes -- scikit-learn's own order of summation is a third one; the sixteen
@@ -368,24 +495,47 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                 for (int tau = 0; tau < nb; ++tau) {
                     const PolyModel m = sh_model[tau];
                     int cnt = 0; double sy = 0.0;
-                    for (int i0 = 0; i0 < n; i0 += 64) {
-                        const int i = i0 + lane;
-                        const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
-                        const bool in = i < n && fabs(yi - poly_predict(m, degree, tp[i < n ? i : 0])) <= thr;
-                        cnt += __popcll(__ballot(in));
-                        sy += in ? yi : 0.0;
+                    if (in_regs) {
+#pragma unroll
+                        for (int k = 0; k < PF_TILE; ++k) {
+                            if (k * 64 < n) {                             // wave-uniform
+                                const bool in = (k * 64 + lane < n) && fabs(yv[k] - poly_predict(m, degree, tv[k])) <= thr;
+                                cnt += __popcll(__ballot(in));
+                                sy += in ? yv[k] : 0.0;
+                            }
+                        }
+                    } else {
+                        for (int i0 = 0; i0 < n; i0 += 64) {
+                            const int i = i0 + lane;
+                            const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
+                            const bool in = i < n && fabs(yi - poly_predict(m, degree, tp[i < n ? i : 0])) <= thr;
+                            cnt += __popcll(__ballot(in));
+                            sy += in ? yi : 0.0;
+                        }
                     }
                     double score = NAN;
                     if (cnt >= 2) {                                           // wave-uniform
                         const double ym = wave_sum(sy) / (double)cnt;
                         double ss_res = 0.0, ss_tot = 0.0;
-                        for (int i0 = 0; i0 < n; i0 += 64) {
-                            const int i = i0 + lane;
-                            const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
-                            const double pr = poly_predict(m, degree, tp[i < n ? i : 0]);
-                            const bool in = i < n && fabs(yi - pr) <= thr;
-                            ss_res += in ? (yi - pr) * (yi - pr) : 0.0;
-                            ss_tot += in ? (yi - ym) * (yi - ym) : 0.0;
+                        if (in_regs) {
+#pragma unroll
+                            for (int k = 0; k < PF_TILE; ++k) {
+                                if (k * 64 < n) {
+                                    const double pr = poly_predict(m, degree, tv[k]);
+                                    const bool in = (k * 64 + lane < n) && fabs(yv[k] - pr) <= thr;
+                                    ss_res += in ? (yv[k] - pr) * (yv[k] - pr) : 0.0;
+                                    ss_tot += in ? (yv[k] - ym) * (yv[k] - ym) : 0.0;
+                                }
+                            }
+                        } else {
+                            for (int i0 = 0; i0 < n; i0 += 64) {
+                                const int i = i0 + lane;
+                                const double yi = i < n ? yp[(int64_t)i * 3] : 0.0;
+                                const double pr = poly_predict(m, degree, tp[i < n ? i : 0]);
+                                const bool in = i < n && fabs(yi - pr) <= thr;
+                                ss_res += in ? (yi - pr) * (yi - pr) : 0.0;
+                                ss_tot += in ? (yi - ym) * (yi - ym) : 0.0;
+                            }
                         }
                         ss_res = wave_sum(ss_res); ss_tot = wave_sum(ss_tot);
                         score = ss_tot != 0.0 ? 1.0 - ss_res / ss_tot : (ss_res == 0.0 ? 1.0 : 0.0);
@@ -393,7 +543,8 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                     if (lane == 0) { sh_nin[drawn + tau] = cnt; sh_score[drawn + tau] = score; }
                 }
                 __syncthreads();
-                drawn += nb;
+                PF_ADD(3);
+                drawn += nb; last_nb = nb;
                 raw_base = sh_end[drawn - 1];
                 while ((double)ntr < max_tr && ntr < drawn) {
                     const int k = ntr++;
@@ -405,6 +556,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                     max_tr = fmin(max_tr, dynamic_max_trials(best_n, n, ms, stop_prob));
                 }
                 __syncthreads();
+                PF_ADD(4);
             }
             const int skip = ntr > 0 ? sh_end[ntr - 1] : 0;
             // the stream goes back to the window-axis start and forward by what n_trials_ draws consume
@@ -412,13 +564,29 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             pos_mt = (int)snap[MT_N];
             __syncthreads();
             mt_skip(mt, pos_mt, skip, lane);
+            PF_ADD(5);
+#ifdef GSF_PF_TIMING
+            pf_acc[9] += 1;
+#endif
             if (best < 0) { wstat = 1; break; }                           // "RANSAC could not find a valid consensus set": the window fails (ref :228-229)
-            const PolyModel mb = fit_subset(tp, yp, sh_idx + (size_t)best * ms, ms, degree, 3);
-            for (int i = lane; i < n; i += 64) {
-                const bool in = fabs(yp[(int64_t)i * 3] - poly_predict(mb, degree, tp[i])) <= thr;
-                if (!in) keep[r_base + r0 + i] &= (uint8_t)~2u;
+            // the winner's model: still in LDS when the winner belongs to the batch scored last (the usual case: the first batch decides), else fitted
+            // again -- same function, same rows, same bits either way
+            const int batch0 = drawn - last_nb;
+            const PolyModel mb = best >= batch0 ? sh_model[best - batch0] : fit_subset<true>(tp, yp, sh_idx + (size_t)best * ms, ms, degree, 3);
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < PF_TILE; ++k) {
+                    const int i = k * 64 + lane;
+                    if (k * 64 < n && i < n && !(fabs(yv[k] - poly_predict(mb, degree, tv[k])) <= thr)) keep[r_base + r0 + i] &= (uint8_t)~2u;
+                }
+            } else {
+                for (int i = lane; i < n; i += 64) {
+                    const bool in = fabs(yp[(int64_t)i * 3] - poly_predict(mb, degree, tp[i])) <= thr;
+                    if (!in) keep[r_base + r0 + i] &= (uint8_t)~2u;
+                }
             }
             __syncthreads();
+            PF_ADD(6);
         }
         for (int i = lane; i < n; i += 64) {
             const uint8_t v = keep[r_base + r0 + i];
@@ -479,7 +647,13 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
         }
     }
     for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
+#ifdef GSF_PF_TIMING
+    pf_acc[10] = clock64() - pf_start;
+    if (lane == 0 && log_info) { for (int k = 0; k < 12; ++k) log_info[b * 16 + k] = (int32_t)(pf_acc[k] > 0x7fffffff ? 0x7fffffff : pf_acc[k]); st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; }
+    (void)processed; (void)succeeded;
+#else
     if (lane == 0) { st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; if (log_info) { log_info[b * 2] = processed; log_info[b * 2 + 1] = succeeded; } }
+#endif
 }
 
 }  // namespace

@@ -154,7 +154,7 @@ public:
 
 private:
     struct Out { void* host; size_t off, bytes; };
-    static constexpr int MAX_OUT = 16;
+    static constexpr int MAX_OUT = 24;
     void* take(size_t bytes, size_t& at);
     void* in_bytes(const void* host, size_t bytes);
     void* out_bytes(void* host, size_t bytes);

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(64) void robust_finish_kernel(int64_t N, const int3
             quat_out[(base + i) * 4] = NAN; quat_out[(base + i) * 4 + 1] = NAN; quat_out[(base + i) * 4 + 2] = NAN; quat_out[(base + i) * 4 + 3] = NAN;
         }
         const int32_t few = rows_status ? (rows_status[b] & SIM3_FLAG_FEW_ROWS) : 0;      // the reference raised ValueError before the fit (:975, :997)
-        if (lane == 0) status[b] = ((f & 1) ? ((SIM3_NONE | few) << 8) : 0) | ((f & 2) ? ST_BAD_QUAT : 0);
+        // (a trajectory the probe decided keeps its SATURATED bit when the fit then fails -- every row counted, but fewer rows than
+        // min_inliers_needed, or a final fit that is None: its generator did stop early, and the bit is what says so)
+        if (lane == 0) status[b] = ((f & 1) ? ((SIM3_NONE | few | sat) << 8) : (sat << 8)) | ((f & 2) ? ST_BAD_QUAT : 0);
     } else if (lane == 0) {
         status[b] = (status[b] & 0xff) | ((fit[b] | (rows_status ? rows_status[b] : 0) | sat) << 8);
     }

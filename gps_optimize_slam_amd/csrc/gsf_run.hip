@@ -166,3 +166,44 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
+
+// the same with host arrays (what a cgo / JNI / ctypes caller with its data in host memory calls): one staged upload, the chain, one download
+extern "C" int gsf_run_fusion_batch(gsf_ctx* ctx, const double* ts, const double* pos, const double* quat, int64_t B, int64_t N, const double* gps_t,
+                                    const double* gps_llh, const int64_t* gps_offsets, const gsf_run_config* cfg, uint32_t* mt_state, double* R,
+                                    double* t, double* s, double* pos_out, double* quat_out, int32_t* status, int32_t* n_inliers, int32_t* zone,
+                                    int32_t* south, double* gps_utm, uint8_t* gps_keep, double* aligned, uint8_t* valid, double* sim3_pos,
+                                    double* err_stats, int32_t* run_status, uint8_t* inlier_mask, int32_t* trial_info)
+{
+    GSF_REQUIRE(ctx && cfg && B >= 0 && N >= 0 && gps_offsets && mt_state, "bad arguments");
+    if (B == 0 || N == 0) return GSF_OK;
+    GSF_REQUIRE(ts && pos && quat && R && t && s && pos_out && quat_out && status && n_inliers && zone && south && aligned && valid && err_stats && run_status,
+                "NULL array");
+    const int64_t total = gps_offsets[B];
+    GSF_REQUIRE(total >= 0 && (total == 0 || (gps_t && gps_llh && gps_utm && gps_keep)), "bad gps_offsets / NULL GNSS array");
+    int64_t max_fixes = 0;
+    for (int64_t b = 0; b < B; ++b) { const int64_t g = gps_offsets[b + 1] - gps_offsets[b]; GSF_REQUIRE(g >= 0, "gps_offsets must not decrease"); if (g > max_fixes) max_fixes = g; }
+    GSF_REQUIRE(max_fixes <= 0x7fffffff, "a log is too long");
+    const size_t P = (size_t)B * (size_t)N, nb = (size_t)B, T = (size_t)total;
+    Staging st(ctx, P * (64 + 56 + 24 + 1 + 24 + 1) + T * (8 + 24 + 24 + 1) + nb * (8 + 625 * 8 + 13 * 8 + 5 * 4 + 96 + 8) + 4096, 24);
+    if (st.rc()) return st.rc();
+    const double* dts = st.in(ts, P); const double* dpos = st.in(pos, P * 3); const double* dquat = st.in(quat, P * 4);
+    const double* dgt = st.in(gps_t, T); const double* dllh = st.in(gps_llh, T * 3); const int64_t* doff = st.in(gps_offsets, nb + 1);
+    const uint32_t* dst_in = st.in(mt_state, nb * 625);
+    uint32_t* dstate = st.out(mt_state, nb * 625);
+    double* dR = st.out(R, nb * 9); double* dt = st.out(t, nb * 3); double* ds = st.out(s, nb);
+    double* dpo = st.out(pos_out, P * 3); double* dqo = st.out(quat_out, P * 4); int32_t* dstat = st.out(status, nb); int32_t* dni = st.out(n_inliers, nb);
+    int32_t* dzone = st.out(zone, nb); int32_t* dsouth = st.out(south, nb);
+    double* dutm = st.out(gps_utm, T * 3); uint8_t* dkeep = st.out(gps_keep, T);
+    double* dal = st.out(aligned, P * 3); uint8_t* dva = st.out(valid, P);
+    double* dsp = sim3_pos ? st.out(sim3_pos, P * 3) : nullptr;
+    double* derr = st.out(err_stats, nb * 12); int32_t* drs = st.out(run_status, nb);
+    uint8_t* dmask = inlier_mask ? st.out(inlier_mask, P) : nullptr;
+    int32_t* dinfo = trial_info ? st.out(trial_info, nb * 2) : nullptr;
+    int rc = st.upload();
+    if (rc) return rc;
+    GSF_HIP(hipMemcpyAsync(dstate, dst_in, nb * 625 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = gsf_run_fusion_batch_dev(ctx, dts, dpos, dquat, B, N, dgt, dllh, doff, total, (int32_t)max_fixes, cfg, dstate, dR, dt, ds, dpo, dqo, dstat, dni, dzone, dsouth,
+                                  dutm, dkeep, dal, dva, dsp, derr, drs, dmask, dinfo);
+    if (rc) return rc;
+    return st.finish();
+}

@@ -265,9 +265,10 @@ GSF_API int gsf_ransac_poly_batch(gsf_ctx *ctx, const double *t, const double *y
    in/out) exactly as scikit-learn's sample_without_replacement draws them, RANSACRegressor's acceptance walk, the stream rewound to
    where n_trials_ draws leave it; a failing axis drops its window and consumes nothing further for it (ref :228-229).
    keep[total] = OR over successful windows of the AND over axes; win_status[w] = 0 ok / 1 no consensus / 2 fewer rows than
-   min_samples (not processed) / 3 not handled; log_status[b] = 2 when a window's min_samples/n lies outside (0.01, 0.99) --
-   scikit-learn then samples by another method that is not restated here -- and the caller has to take the fed-sample route
-   (gsf_ransac_poly_batch_dev) for that log from its saved generator state.  max_trials <= 1024, min_samples <= 16, degree <= 3. */
+   min_samples (not processed) / 3 not handled; log_status[b] = 2 when a window's min_samples/n is 0.01 or less -- scikit-learn then
+   samples by tracking selection, which is not restated here -- and the caller has to take the fed-sample route
+   (gsf_ransac_poly_batch_dev) for that log from its saved generator state.  (A window of exactly min_samples rows, ratio 1, is handled:
+   scikit-learn's reservoir sampling then returns rows 0 .. min_samples-1 without a draw.)  max_trials <= 1024, min_samples <= 16, degree <= 3. */
 GSF_API int gsf_gps_prefilter_chain_dev(gsf_ctx *ctx, const double *t, const double *pos, const int64_t *offsets, int64_t B,
                                         const int32_t *win_rows, const int64_t *win_offsets, int32_t max_window_rows, int32_t max_trials,
                                         int32_t min_samples, int32_t degree, double residual_threshold, double stop_probability,
@@ -434,6 +435,12 @@ GSF_API int gsf_run_fusion_batch_dev(gsf_ctx *ctx, const double *ts, const doubl
                                      double *pos_out, double *quat_out, int32_t *status, int32_t *n_inliers, int32_t *zone, int32_t *south,
                                      double *gps_utm, uint8_t *gps_keep, double *aligned, uint8_t *valid, double *sim3_pos,
                                      double *err_stats, int32_t *run_status, uint8_t *inlier_mask, int32_t *trial_info);
+/* the same with host arrays (gps_llh must be given; total_fixes and max_fixes are read from gps_offsets) */
+GSF_API int gsf_run_fusion_batch(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, int64_t B, int64_t N, const double *gps_t,
+                                 const double *gps_llh, const int64_t *gps_offsets, const gsf_run_config *cfg, uint32_t *mt_state, double *R,
+                                 double *t, double *s, double *pos_out, double *quat_out, int32_t *status, int32_t *n_inliers, int32_t *zone,
+                                 int32_t *south, double *gps_utm, uint8_t *gps_keep, double *aligned, uint8_t *valid, double *sim3_pos,
+                                 double *err_stats, int32_t *run_status, uint8_t *inlier_mask, int32_t *trial_info);
 
 /* ragged forms (trajectories of different lengths): flat [total][C] arrays, trajectory b = rows offsets[b]..offsets[b+1] */
 GSF_API int gsf_ekf_fuse_ragged_dev(gsf_ctx *ctx, const double *ts, const double *pos, const double *quat, const double *gps,

@@ -1181,6 +1181,34 @@ def test_gps_ransac_problems_vs_live_sklearn(E):
         assert after == ref_after, case
 
 
+def test_prefilter_windows_of_exactly_min_samples_rows(E, orc):
+    """A window that holds exactly min_samples fixes (the tail of a log, a sparse log): scikit-learn's sampler leaves its permutation range
+    (min_samples / n = 1) and returns rows 0 .. min_samples-1 by reservoir sampling WITHOUT a draw.  The device chain restates that (round 5;
+    before, such a log went to the window-by-window host route): same rows kept and same generator position as the oracle, which calls
+    scikit-learn's own sampler -- on sparse logs whose sliding windows shrink to min_samples rows and below."""
+    rng = np.random.default_rng(19)
+    hit = 0
+    for case in range(40):
+        n = int(rng.integers(8, 40)); ms = int(rng.choice([4, 6, 8]))
+        cfg = {"enabled": True, "use_sliding_window": True, "window_duration_seconds": float(rng.choice([1.5, 3.0, 6.0])), "window_step_factor": float(rng.choice([0.25, 0.5, 1.0])),
+               "polynomial_degree": int(rng.choice([1, 2])), "min_samples": ms, "residual_threshold_meters": float(rng.choice([2.0, 10.0])), "max_trials": 30}
+        t = np.cumsum(rng.uniform(0.2, 0.6, n))
+        p = np.column_stack((4.5e5 + 9.0 * t, 5.4e6 - 4.0 * t + 0.3 * t * t, 110.0 + 0.1 * t)) + rng.normal(0, 0.3, (n, 3))
+        p[rng.choice(n, size=2, replace=False)] += rng.normal(0, 40.0, (2, 3))
+        ranges, _ = E._prefilter_windows(t, cfg, ms)
+        hit += int(any(b - a == ms for a, b in (ranges or [])))
+        np.random.seed(case)
+        ft_o, fp_o = orc.filter_gps_outliers_ransac(t, p, cfg)
+        after_o = np.random.random()
+        np.random.seed(case)
+        ft, fp = E.filter_gps_outliers_ransac(t, p, cfg)
+        after = np.random.random()
+        np.testing.assert_array_equal(ft, ft_o, err_msg=f"case {case}: n={n} ms={ms} {cfg}")
+        np.testing.assert_array_equal(fp, fp_o)
+        assert after == after_o, case
+    assert hit >= 15                                                       # the n == min_samples windows really occur
+
+
 def test_configs_beyond_the_fast_kernels_take_the_wide_routes(E):
     """Any CONFIG the reference accepts runs (no GsfError for being out of a kernel's range): polynomial_degree 4-5, min_samples 10-24
     and max_trials 1 500-3 000 in the GPS pre-filter take the wide fed-sample kernel (host draws by scikit-learn's sampler) and still
@@ -1744,6 +1772,29 @@ def test_robust_early_exit_equals_the_full_chain_bit_for_bit(B, nb, N, probe):
     assert not sat[hit].any() and (nb < 100 or (sat.sum() > nb // 2))           # the 30 m fixes keep their tracks going; most clean tracks stop early
     print(f"[early exit {nb} x {N}, probe {probe}] saturated {int(sat.sum())}/{nb}; trials drawn by saturated tracks: "
           f"{torch.bincount(infoe[sat, 1].long()).nonzero().ravel().tolist()} -> {torch.bincount(infoe[sat, 1].long())[torch.bincount(infoe[sat, 1].long()) > 0].tolist()}")
+
+
+@pytest.mark.gpu
+def test_early_exit_keeps_its_flag_when_the_fit_then_fails(B):
+    """A trajectory whose first trials count every row stops drawing -- also when the reference then returns None because there are fewer rows
+    than min_inliers_needed (ref :416-418, after the loop): the same NaN outputs and n_inliers as the chain that draws every trial, and the
+    SATURATED bit next to GSF_SIM3_NONE says that its generator stopped early (found by tests/campaigns/stress_run_chain.py: the bit used to be
+    dropped on this branch, so a caller could not tell which generators had moved by fewer trials)."""
+    import copy
+    import torch
+    cfg = copy.deepcopy(B.CONFIG)
+    cfg["sim3_ransac"]["min_inliers_needed"] = 400                      # more than a 271-pose track can hold
+    bt = B.TrajectoryBatch.synthetic(300, 271, layout=0, seed=31)
+    seeds = torch.arange(300, dtype=torch.int64) + 5
+    st_f, st_e = B.mt19937_seed(seeds), B.mt19937_seed(seeds)
+    of, Rf, tf, sf, nf, mf, inf_f = B.fuse_pipeline_robust_batch(bt, st_f, cfg, early_exit=False, return_info=True)
+    oe, Re, te, se, ne, me, inf_e = B.fuse_pipeline_robust_batch(bt, st_e, cfg, early_exit=True, return_info=True)
+    assert torch.isnan(of.pos).all() and torch.isnan(oe.pos).all() and torch.isnan(Re).all()
+    assert torch.equal(nf, ne) and torch.equal(mf, me) and torch.equal(inf_f[:, 0], inf_e[:, 0])
+    sat = ((oe.status >> 8) & 256) != 0
+    assert ((oe.status >> 8) & 1).all() and ((of.status >> 8) & 1).all() and torch.equal(of.status, oe.status & ~(256 << 8))
+    assert sat.sum() > 250 and (inf_e[sat, 1] % 8 == 0).all() and (inf_e[sat, 1] <= 64).all() and (inf_f[:, 1] == cfg["sim3_ransac"]["max_trials"]).all()
+    assert torch.equal(st_f[~sat], st_e[~sat]) and not torch.equal(st_f[sat], st_e[sat])
 
 
 @contextlib.contextmanager

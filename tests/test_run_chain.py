@@ -96,6 +96,28 @@ def test_stacked_c1_goldens_and_the_drop_in(B, golden, tmp_path, tag):
             e = d["errors"]["primary"][lab]
             assert int(stats[row, c, 0]) == e["count"]
             np.testing.assert_allclose(stats[row, c, 1:], [e["mean"], e["median"], e["rmse"]], rtol=1e-12, atol=1e-9)
+    # ---- the host-pointer form of the chain (gsf_run_fusion_batch: what a C / cgo / JNI caller with host arrays calls): the same bits
+    from gps_optimize_slam_amd import _lib
+    L, ctx, hp = _lib.load(), B.context(), _lib.hptr
+    ctx.set_option("ransac_early_exit", 0)
+    rc = _lib.RunConfig.from_config(E.CONFIG)
+    a = lambda x, dt=np.float64: np.ascontiguousarray(x, dtype=dt)
+    h_ts, h_pos, h_quat = a(rep(k["ts"])), a(rep(k["pos"])), a(rep(k["quat"]))
+    h_gt, h_llh = a(np.tile(log[:, 0], copies)), a(np.tile(log[:, 1:4], (copies, 1)))
+    h_off = np.arange(copies + 1, dtype=np.int64) * n
+    h_st = B.mt19937_seed([0] * copies).cpu().numpy().copy()
+    o = dict(R=np.empty((copies, 9)), t=np.empty((copies, 3)), s=np.empty(copies), po=np.empty((copies, N, 3)), qo=np.empty((copies, N, 4)),
+             st=np.empty(copies, np.int32), ni=np.empty(copies, np.int32), zone=np.empty(copies, np.int32), south=np.empty(copies, np.int32),
+             utm=np.empty((copies * n, 3)), keep=np.empty(copies * n, np.uint8), al=np.empty((copies, N, 3)), va=np.empty((copies, N), np.uint8),
+             sp=np.empty((copies, N, 3)), err=np.empty((3, copies, 4)), rs=np.empty(copies, np.int32), mask=np.empty((copies, N), np.uint8),
+             info=np.empty((copies, 2), np.int32))
+    _lib.check(L.gsf_run_fusion_batch(ctx.handle, hp(h_ts), hp(h_pos), hp(h_quat), copies, N, hp(h_gt), hp(h_llh), hp(h_off), C.byref(rc), hp(h_st),
+                                      *[hp(o[k_]) for k_ in ("R", "t", "s", "po", "qo", "st", "ni", "zone", "south", "utm", "keep", "al", "va", "sp", "err", "rs", "mask", "info")]))
+    for got, dev in ((o["po"], p), (o["qo"], q), (o["st"], status), (o["R"], r.R.cpu().numpy()), (o["s"], r.s.cpu().numpy()), (o["ni"], r.n_inliers.cpu().numpy()),
+                     (o["utm"], r.gps_utm.cpu().numpy()), (o["keep"], r.gps_keep.cpu().numpy()), (o["al"], np.nan_to_num(al, nan=-1.0)), (o["va"], r.valid.cpu().numpy()),
+                     (o["sp"], r.sim3_pos.cpu().numpy()), (o["err"], stats), (o["rs"], r.run_status.cpu().numpy()), (o["mask"], r.inlier_mask.cpu().numpy()),
+                     (o["info"], r.trial_info.cpu().numpy()), (h_st.view(np.int32), st.cpu().numpy())):
+        np.testing.assert_array_equal(np.nan_to_num(got, nan=-1.0) if got.dtype == np.float64 else got, dev)
 
 
 def test_headless_main_process_gui_runs_through_the_chain(B, golden):
@@ -177,7 +199,7 @@ def _oracle_run(orc, ts, pos, quat, log, cfg, seed):
     R, t, s, mask = res
     sp, sq = orc.transform_trajectory(pos, quat, R, t, s)
     po, qo, sto = orc.apply_ekf_correction_aligned(ts, pos, quat, al, va, sp[0], sq[0], cfg, return_status=True)
-    out.update(R=R, t=t, s=s, n_inliers=int(mask.sum()), pos=po, quat=qo, st=sto, sim3_pos=sp,
+    out.update(R=R, t=t, s=s, n_inliers=int(mask.sum()), fit_rows=rows[mask], pos=po, quat=qo, st=sto, sim3_pos=sp,
                errs=[orc.evaluate_trajectory_errors(ts, tr, al, va) for tr in (pos, sp, po)])
     return out
 

@@ -3,7 +3,7 @@
 usage: python tools/collect_profiles.py r01"""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw, out = os.path.join(root, "gpurun_out", "profiles_raw"), os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -21,7 +21,8 @@ traffic = {"kernel_source_hash": bench.kernel_source_hash()}
 pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_big_kernel<[\w, ]+>|ekf_wave_duo_kernel<[\w, ]+>|ekf_block_kernel<[\w, ]+>|windows_fused_kernel|windows_moments_kernel|windows_finalize_kernel|sim3_rows_kernel|fuse_pipeline_kernel<[\w, ]+>|ekf_fuse_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
                  r"apply_sim3_kernel|apply_sim3_slab_kernel|utm_kernel<\w+>|gps_rows_to_utm_kernel|enu_kernel|time_align_kernel|eval_errors_kernel|eval_errors_lds_kernel|ransac_poly_kernel|mt_choice_kernel|"
                  r"ransac_rows_kernel|ransac_scan_kernel|ransac_finish_kernel|mt_tape_kernel|mt_transition_kernel|mt_compose_kernel|mt_expand_kernel|mt_resolve_kernel|mt_tape_trace_kernel|"
-                 r"compact_valid_kernel|transpose_kernel<[\w, ]+>)")
+                 r"compact_valid_kernel|transpose_kernel<[\w, ]+>|robust_probe_kernel|gps_prefilter_chain_kernel|run_compact_rows_kernel|run_filtered_rows_kernel|run_outcome_kernel|"
+                 r"robust_init_pose_kernel|robust_finish_kernel)")
 kt_aux = sorted(glob.glob(raw + "/trace_aux/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime, reverse=True)
 if kt_aux:
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), kt_aux[0], f"{out}/{tag}_aux_by_kernel_and_grid.csv"])
