@@ -24,6 +24,64 @@ def exe():
     return out
 
 
+@pytest.fixture(scope="module")
+def exe_run():
+    from gps_optimize_slam_amd import _lib
+    if not os.path.exists(_lib.library_path()):
+        _lib.build_library()
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "run_fusion")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "run_fusion.c"), "-o", out, "-L" + PKG, "-lgsf", "-Wl,-rpath," + PKG])
+    return out
+
+
+def test_run_fusion_consumer_builds_and_fails_loudly_without_a_device(exe_run, tmp_path):
+    from gps_optimize_slam_amd import _lib
+    if _lib.load().gsf_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([1, 4, 2], dtype=np.int64).tofile(f)
+        for n in (4, 12, 16):
+            np.zeros(n).tofile(f)
+        np.array([0, 2], dtype=np.int64).tofile(f); np.zeros(2).tofile(f); np.zeros(6).tofile(f)
+    r = subprocess.run([exe_run, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+@pytest.mark.gpu
+def test_run_fusion_consumer_equals_the_python_route(exe_run, tmp_path):
+    """examples/run_fusion.c (gsf_run_fusion_batch on host arrays, its generators seeded in C like np.random.seed) against batch.run_fusion_batch on
+    the same synthetic geodetic logs: every output word."""
+    import torch
+    from gps_optimize_slam_amd import batch as B
+    nb, N = 40, 271
+    gb = B.GeodeticBatch.synthetic(nb, N, seed=5)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([nb, N, gb.gps_t.numel()], dtype=np.int64).tofile(f)
+        for a in (gb.ts, gb.pos, gb.quat, gb.gps_offsets, gb.gps_t, gb.gps_llh):
+            a.cpu().numpy().tofile(f)
+    r = subprocess.run([exe_run, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "7"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"ran {nb} trajectories x {N} poses" in r.stdout and "0 runs the reference would have aborted" in r.stdout
+    raw = open(tmp_path / "out.bin", "rb").read()
+    P, T = nb * N, gb.gps_t.numel()
+    nd = nb * 13 + P * 7 + nb * 12
+    fl = np.frombuffer(raw[:8 * nd], dtype=np.float64)
+    it = np.frombuffer(raw[8 * nd:8 * nd + 16 * nb], dtype=np.int32).reshape(4, nb)
+    keep = np.frombuffer(raw[8 * nd + 16 * nb:], dtype=np.uint8)
+    st = B.mt19937_seed(np.arange(nb) + 7)
+    res = B.run_fusion_batch(gb, st, early_exit=False)
+    p, q, status = res.fused.host_traj_major()
+    o = 0
+    for ref in (res.R.cpu().numpy(), res.t.cpu().numpy(), res.s.cpu().numpy(), p, q, res.err_stats.cpu().numpy()):
+        np.testing.assert_array_equal(np.nan_to_num(fl[o:o + ref.size], nan=-1.0), np.nan_to_num(ref.ravel(), nan=-1.0)); o += ref.size
+    for k, ref in enumerate((status, res.n_inliers.cpu().numpy(), res.zone.cpu().numpy(), res.run_status.cpu().numpy())):
+        np.testing.assert_array_equal(it[k], ref)
+    np.testing.assert_array_equal(keep, res.gps_keep.cpu().numpy())
+    assert len(keep) == T
+
+
 def test_header_is_plain_c_and_cxx():
     h = os.path.join(ROOT, "include", "gsf.h")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", h])

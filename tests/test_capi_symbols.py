@@ -38,9 +38,27 @@ def test_version_and_abi(lib):
     assert b"gfx950" in L.gsf_version()
 
 
-def test_config_struct_layout(lib):
+def test_config_struct_layout(lib, tmp_path):
     # gsf_ekf_config: 7+7+3 doubles, 1 double, 2 int32
     assert C.sizeof(lib.EkfConfig) == 17 * 8 + 8 + 8
+    # every POD of the boundary: size and the offset of every field as gcc lays the header's struct out == the ctypes mirror in _lib.py
+    import subprocess
+    structs = {"gsf_ekf_config": lib.EkfConfig, "gsf_prefilter_config": lib.PrefilterConfig, "gsf_run_config": lib.RunConfig}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gsf.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in subprocess.check_output([str(exe)], text=True).splitlines()}
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_fails_loudly_without_gpu(lib):
