@@ -81,6 +81,90 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
     }
 }
 
+// min / sum over the S adjacent lanes that share a query (S = 1 .. 64, wave-uniform): DPP inside a 16-lane row, ds_bpermute beyond
+__device__ __forceinline__ double group_min(double v, const int S)
+{
+    if (S > 1) v = fmin(v, dpp_quad<0xB1>(v));
+    if (S > 2) v = fmin(v, dpp_quad<0x4E>(v));
+    if (S > 4) v = fmin(v, dpp_row_xor<4>(v));
+    if (S > 8) v = fmin(v, dpp_row_xor<8>(v));
+    if (S > 16) v = fmin(v, __shfl_xor(v, 16, 64));
+    if (S > 32) v = fmin(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ int group_sum(int v, const int S)
+{
+    if (S > 1) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    if (S > 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    if (S > 4) { int o = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false); o = __builtin_amdgcn_update_dpp(o, v, 0x114, 0xf, 0xa, false); v += o; }
+    if (S > 8) { int o = __builtin_amdgcn_update_dpp(0, v, 0x108, 0xf, 0x3, false); o = __builtin_amdgcn_update_dpp(o, v, 0x118, 0xf, 0xc, false); v += o; }
+    if (S > 16) v += __shfl_xor(v, 16, 64);
+    if (S > 32) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// nearest fix of the TQ queries q0 + u * G of this thread over its candidates part, part + S, ... (:1030-1031); queries beyond M compute on
+// row 0 and are dropped
+template <int TQ>
+__device__ __forceinline__ void eval_nearest(const double* __restrict__ p, const double* cx, const double* cy, const double* cz, double* cerr,
+                                             const int32_t* qidx, double* __restrict__ e, const int M, const int S, const int part, const int q0, const int G,
+                                             double& cnt, double& sum, double& sum2)
+{
+    double qx[TQ], qy[TQ], qz[TQ], best[TQ];
+    int rows[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int q = q0 + u * G;
+        rows[u] = q < M ? qidx[q] : 0;
+        qx[u] = p[(int64_t)rows[u] * 3]; qy[u] = p[(int64_t)rows[u] * 3 + 1]; qz[u] = p[(int64_t)rows[u] * 3 + 2];
+        best[u] = INFINITY;
+    }
+#pragma unroll 2
+    for (int k = part; k < M; k += S) {
+        const double gx = cx[k], gy = cy[k], gz = cz[k];
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            const double dx = qx[u] - gx, dy = qy[u] - gy, dz = qz[u] - gz;
+            best[u] = fmin(best[u], dx * dx + dy * dy + dz * dz);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const double bu = group_min(best[u], S);
+        const int q = q0 + u * G;
+        if (q < M && part == 0) {
+            const double err = sqrt(bu);
+            cerr[q] = err; e[rows[u]] = err;
+            cnt += 1.0; sum += err; sum2 += err * err;
+        }
+    }
+}
+
+// ranks of the same queries' errors among all M errors (ties by row order); the two middle order statistics go to sh_med
+template <int TQ>
+__device__ __forceinline__ void eval_median(const double* cerr, const int M, const int S, const int part, const int q0, const int G, double* sh_med)
+{
+    const int k_lo = (M - 1) / 2, k_hi = M / 2;
+    double ei[TQ];
+    int rank[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) { const int q = q0 + u * G; ei[u] = q < M ? cerr[q] : 0.0; rank[u] = 0; }
+#pragma unroll 2
+    for (int k = part; k < M; k += S) {
+        const double ej = cerr[k];
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) rank[u] += (int)(ej < ei[u]) | ((int)(ej == ei[u]) & (int)(k < q0 + u * G));
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int r = group_sum(rank[u], S);
+        if (q0 + u * G < M && part == 0 && !isnan(ei[u])) {
+            if (r == k_lo) sh_med[0] = ei[u];
+            if (r == k_hi) sh_med[1] = ei[u];
+        }
+    }
+}
+
 // The same metric for tracks of up to EVAL_LDS_MAX_N poses (every BASELINE config): the candidate set is compacted into LDS once
 // (coordinates, original index, later the errors), and the M x M pair work -- nearest fix, then the rank count of the median -- is
 // spread evenly: S adjacent lanes share a query (S = a power of two with M*S ~ 2 000 work items for the 256 threads), each walking
@@ -88,6 +172,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
 // one-thread-per-query kernel's bit for bit; the sums of the mean / RMSE keep that kernel's order of partial sums only up to the
 // last digits (gate 1e-9 m in the tests).  271 poses: 111 -> ~25 us for one track, 139 -> ~60 us for 1 000.
 constexpr int EVAL_LDS_MAX_N = 1536;
+#ifdef GSF_EVAL_TIMING   // diagnostic build (make eval_timing): shader-clock stamps of the phases land in errors[b * N + 0 .. 9] instead of the errors
+#define EV_T(k) do { if (tid == 0) ev_t[k] = clock64(); } while (0)
+#else
+#define EV_T(k) do { } while (0)
+#endif
 // up to three trajectories per track against the SAME fixes in one launch (step 6 prints raw SLAM / Sim3 / EKF, ref :1027): blockIdx.y picks
 // the set; stats / errors of set k start at k * B * 4 / k * B * N
 struct EvalSets { const double* traj[3]; };
@@ -109,6 +198,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
     double* e = errors + b * N;
     double* cx = dynl; double* cy = cx + n; double* cz = cy + n; double* cerr = cz + n;
     int32_t* qidx = (int32_t*)(cerr + n);
+#ifdef GSF_EVAL_TIMING
+    long long ev_t[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const long long ev_w0 = wall_clock64();                              // 100 MHz, common to the chip
+#endif
+    EV_T(0);
     const double thr = t[0] + skip;                                      // :1018
     // ---- candidate / query set (:1016-1021), compacted in row order
     int base = 0;
@@ -131,63 +225,57 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
         base += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
         __syncthreads();
     }
+    EV_T(1);
     const int M = base;                                                  // block-uniform
     int S = 1;
     while (S < 64 && M * (S * 2) <= 2048) S *= 2;
     const int part = tid & (S - 1);
+    // Query tile: a thread keeps ALL its queries (one per pass of the old form: q = tid / S + u * 256 / S, at most 8 since M * S <= 2 048)
+    // in registers and walks its candidates once, so a candidate's LDS reads serve the whole tile, and the inner loops are straight-line code (the
+    // old form's short-circuit tie rule compiled to exec-mask branches: 140 cycles per candidate of the rank pass, in-kernel clocks of the
+    // eval_timing build).  min and the rank counts are order-independent and the per-thread sums run over the passes in the old order: the same bits.
+    const int G = EVAL_THREADS / S, q0 = tid / S;                        // S divides 64 and 256: the S lanes of a query sit side by side in one wave
+    const int passes = (M * S + EVAL_THREADS - 1) / EVAL_THREADS;         // block-uniform, <= 8
     // ---- nearest fix of every query (:1030-1031)
     double cnt = 0.0, sum = 0.0, sum2 = 0.0;
-    for (int it0 = 0; it0 < M * S; it0 += EVAL_THREADS) {
-        const int q = (it0 + tid) / S;                                   // S divides 64 and 256: the S lanes of a query sit side by side in one wave
-        const bool live = q < M;
-        const int row = live ? qidx[q] : 0;
-        const double x = p[(int64_t)row * 3], y = p[(int64_t)row * 3 + 1], z = p[(int64_t)row * 3 + 2];
-        double best = INFINITY;
-        if (live) {
-#pragma unroll 4
-            for (int k = part; k < M; k += S) {
-                const double dx = x - cx[k], dy = y - cy[k], dz = z - cz[k];
-                best = fmin(best, dx * dx + dy * dy + dz * dz);
-            }
-        }
-        for (int o = 1; o < S; o <<= 1) best = fmin(best, __shfl_xor(best, o, 64));
-        if (live && part == 0) {
-            const double err = sqrt(best);
-            cerr[q] = err; e[row] = err;
-            cnt += 1.0; sum += err; sum2 += err * err;
-        }
+    EV_T(2);
+    switch (passes) {                                                    // block-uniform; the tile is exactly as long as the passes
+    case 0: case 1: eval_nearest<1>(p, cx, cy, cz, cerr, qidx, e, M, S, part, q0, G, cnt, sum, sum2); break;
+#define GSF_EVAL_CASE(T) case T: eval_nearest<T>(p, cx, cy, cz, cerr, qidx, e, M, S, part, q0, G, cnt, sum, sum2); break;
+    GSF_EVAL_CASE(2) GSF_EVAL_CASE(3) GSF_EVAL_CASE(4) GSF_EVAL_CASE(5) GSF_EVAL_CASE(6) GSF_EVAL_CASE(7)
+#undef GSF_EVAL_CASE
+    default: eval_nearest<8>(p, cx, cy, cz, cerr, qidx, e, M, S, part, q0, G, cnt, sum, sum2); break;
     }
+    EV_T(4);
     const double Mf = block_reduce_sum(cnt, sh, tid);
     const double S1 = block_reduce_sum(sum, sh, tid);
     const double S2 = block_reduce_sum(sum2, sh, tid);
     if (tid == 0) { sh_med[0] = NAN; sh_med[1] = NAN; }
     __syncthreads();                                                     // cerr[] complete
-    // ---- np.median: the two middle order statistics by rank count (ties broken by row order)
+    EV_T(5);
+    // ---- np.median: the two middle order statistics by rank count (ties broken by row order), the same query tile
     if (M > 0) {
-        const int k_lo = (M - 1) / 2, k_hi = M / 2;
-        for (int it0 = 0; it0 < M * S; it0 += EVAL_THREADS) {
-            const int q = (it0 + tid) / S;
-            const bool live = q < M;
-            const double ei = live ? cerr[q] : 0.0;
-            int rank = 0;
-            if (live) {
-#pragma unroll 4
-                for (int k = part; k < M; k += S) { const double ej = cerr[k]; rank += (ej < ei || (ej == ei && k < q)) ? 1 : 0; }
-            }
-            for (int o = 1; o < S; o <<= 1) rank += __shfl_xor(rank, o, 64);
-            if (live && part == 0 && !isnan(ei)) {
-                if (rank == k_lo) sh_med[0] = ei;
-                if (rank == k_hi) sh_med[1] = ei;
-            }
+        switch (passes) {
+        case 0: case 1: eval_median<1>(cerr, M, S, part, q0, G, sh_med); break;
+#define GSF_EVAL_CASE(T) case T: eval_median<T>(cerr, M, S, part, q0, G, sh_med); break;
+        GSF_EVAL_CASE(2) GSF_EVAL_CASE(3) GSF_EVAL_CASE(4) GSF_EVAL_CASE(5) GSF_EVAL_CASE(6) GSF_EVAL_CASE(7)
+#undef GSF_EVAL_CASE
+        default: eval_median<8>(cerr, M, S, part, q0, G, sh_med); break;
         }
     }
     __syncthreads();
+    EV_T(6);
     if (tid == 0) {
         stats[b * 4] = Mf;
         stats[b * 4 + 1] = M > 0 ? S1 / Mf : NAN;
         stats[b * 4 + 2] = M > 0 ? 0.5 * (sh_med[0] + sh_med[1]) : NAN;
         stats[b * 4 + 3] = M > 0 ? sqrt(S2 / Mf) : NAN;
     }
+#ifdef GSF_EVAL_TIMING
+    EV_T(7);
+    __syncthreads();
+    if (tid == 0) { for (int k = 0; k < 8; ++k) e[k] = (double)(ev_t[k] - ev_t[0]); e[8] = (double)ev_w0; e[9] = (double)wall_clock64(); }
+#endif
 }
 
 }  // namespace

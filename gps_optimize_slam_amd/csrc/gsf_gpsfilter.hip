@@ -379,7 +379,7 @@ __device__ __forceinline__ void score_trial(const double* __restrict__ tp, const
 // either AND the axis mask into the window mask or -- no consensus set: the reference's exception -- drop the window and skip its
 // remaining axes (they consume nothing).  keep[] = OR over the successful windows.  One wave per log.
 constexpr int CH_MAX_TRIALS = 1024;
-constexpr int PF_TILE = 8;            // row iterations of a window held in registers by the chain kernel (64 rows each)
+constexpr int PF_TILE = 4;            // row iterations of a window held in registers by the chain kernel (64 rows each)
 #ifdef GSF_PF_TIMING
 // diagnostic build only (make pf_timing, tools/experiments/prefilter_timing.py): shader-clock totals per phase of the chain, written by lane 0 into
 // log_info[b * 16 + k] (the caller passes 16 ints per log): 0 snapshot, 1 draw, 2 fit, 3 score, 4 walk, 5 rewind, 6 final model + mask, 7 fold,
@@ -396,7 +396,7 @@ constexpr int PF_TILE = 8;            // row iterations of a window held in regi
 // one row range (an unsorted log is flagged 3 and left to the host route).  mode 2: one window = the whole log (ref :148-182).
 // Modes 1 / 2 also take the reference's early-outs: filtering disabled -> every row kept, nothing drawn (:139-141); fewer than `need` rows
 // -> the same (:144-146).
-struct WinGen { int32_t mode, need; double width, stride; int32_t enabled, max_windows; };
+struct WinGen { int32_t mode, need; double width, stride; int32_t enabled, max_windows, first_batch, speculate; };
 __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* __restrict__ t, const double* __restrict__ pos, const int64_t* __restrict__ offsets,
                                                                  const int32_t* __restrict__ counts,
                                                                  const int32_t* __restrict__ win_rows, const int64_t* __restrict__ win_offsets,
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
 #ifdef GSF_PF_TIMING
-    long long pf_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long pf_acc[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const long long pf_start = clock64();
 #endif
     const int64_t r_base = offsets[b];
@@ -432,8 +432,12 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
     }
     for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
     int pos_mt = (int)st[MT_N];
-    for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 0;
+    uint8_t* kp = keep + r_base;                                           // the log's keep bytes
+    for (int i = lane; i < n_log; i += 64) kp[i] = 0;
     __syncthreads();
+#ifdef GSF_PF_TIMING
+    pf_acc[16] = clock64() - pf_start;
+#endif
     int lstat = 0;
     // one window (rows r0 .. r1-1 of the log): 0 ok / 1 no consensus set / 2 fewer rows than min_samples (not processed) / 3 not handled
     auto run_window = [&](const int r0, const int r1) -> int {
@@ -447,19 +451,98 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
         const double ratio = (double)ms / (double)n;
         const bool identity = n == ms;
         if (!identity && (!(ratio > 0.01 && ratio < 0.99) || n > jseq_elems)) { lstat = 2; return 3; }
+#ifdef GSF_PF_TIMING
+        const long long pf_w0 = clock64();
+#endif
         const double* tp = t + r_base + r0;
         // window mask lives in keep[] itself as bit 1 (AND over axes), folded into bit 0 (OR over windows) when the window succeeds
-        for (int i = lane; i < n; i += 64) keep[r_base + r0 + i] |= 2;
+        for (int i = lane; i < n; i += 64) kp[r0 + i] |= 2;
         // the window's rows in registers when they fit (up to 64 x PF_TILE = 512 rows; lane l holds rows l, l + 64, ...): the stamps once per
         // window, an axis's values once per axis -- every trial's two scoring passes and the final mask read them from there instead of memory
         const bool in_regs = n <= 64 * PF_TILE;
-        double tv[PF_TILE], yv[PF_TILE];
+        double tv[PF_TILE], yv[PF_TILE], y3[3][PF_TILE];
+        {
+            // one batch of loads per window: the stamps and all three axes (clamped rows, no branch: every load in flight at once)
+            const double* p3 = pos + (r_base + r0) * 3;
 #pragma unroll
-        for (int k = 0; k < PF_TILE; ++k) { const int i = k * 64 + lane; tv[k] = (in_regs && k * 64 < n) ? tp[i < n ? i : n - 1] : 0.0; yv[k] = 0.0; }
+            for (int k = 0; k < PF_TILE; ++k) {
+                const int i = k * 64 + lane, ic = in_regs ? (i < n ? i : n - 1) : 0;
+                tv[k] = tp[ic]; y3[0][k] = p3[(int64_t)ic * 3]; y3[1][k] = p3[(int64_t)ic * 3 + 1]; y3[2][k] = p3[(int64_t)ic * 3 + 2]; yv[k] = 0.0;
+            }
+        }
+        // ---- speculative pass (round 5).  On a clean window every axis's RANSACRegressor stops after its FIRST trial (the sample's model
+        // counts enough rows for _dynamic_max_trials <= 1), so the three axes consume three CONSECUTIVE trials of the stream.  Draw those three
+        // in one go, fit the three models on three lanes, count their inliers, and evaluate the stopping rule for all three at once: an axis
+        // whose first trial ends its loop is finished exactly as the sequential walk would finish it (one trial considered: the R^2 score
+        // cannot matter, the accepted model is that trial's).  The first axis that needs more trials -- and every axis after it -- goes
+        // through the sequential loop below, from the stream position where that axis starts.  Same words out, ~1/4 of the time per clean window.
+#ifdef GSF_PF_TIMING
+        pf_acc[17] += clock64() - pf_w0 + (long long)(tv[0] == 1.25 ? 1 : 0) + (long long)(y3[2][0] == 1.25 ? 1 : 0);   // (the loads have landed)
+#endif
+        const bool spec_ok = gen.speculate != 0 && !identity && in_regs && max_trials >= 3;
         for (int ax = 0; ax < 3 && wstat == 0; ++ax) {
+          if (spec_ok && ax != 2) {                                       // (a pass over the last axis alone would save nothing)
+            const int na = 3 - ax;                                        // axes ax .. 2: na consecutive trials
+            PF_T0();
+            for (int i = lane; i <= MT_N; i += 64) snap[i] = (i < MT_N) ? mt[i] : (uint32_t)pos_mt;
+            __syncthreads();
+            mt_draw_choice(mt, pos_mt, n, na, ms, jseq, jseq_elems, sh_idx, sh_end, lane);
+            PF_ADD(12);
+            const double* y0 = pos + (r_base + r0) * 3 + ax;
+            if (lane < na) sh_model[lane] = fit_subset<true>(tp, y0 + lane, sh_idx + (size_t)lane * ms, ms, degree, 3);
+            __syncthreads();
+            PF_ADD(13);
+            int cnt3[3] = { 0, 0, 0 };                                    // by ABSOLUTE axis (constant register indices)
+            unsigned inl[PF_TILE];                                        // bit A: the row is an inlier of axis A's model
+#pragma unroll
+            for (int k = 0; k < PF_TILE; ++k) inl[k] = 0u;
+#pragma unroll
+            for (int A = 0; A < 3; ++A) {
+                if (A >= ax) {                                            // wave-uniform
+                    const PolyModel m = sh_model[A - ax];
+#pragma unroll
+                    for (int k = 0; k < PF_TILE; ++k) {
+                        if (k * 64 < n) {                                 // wave-uniform
+                            const bool in = (k * 64 + lane < n) && fabs(y3[A][k] - poly_predict(m, degree, tv[k])) <= thr;
+                            cnt3[A] += __popcll(__ballot(in));
+                            inl[k] |= in ? (1u << A) : 0u;
+                        }
+                    }
+                }
+            }
+            PF_ADD(14);
+            // the walk over ONE trial: skipped if it counts no row (c < 1: the loop would go on), else accepted and max_trials shrinks
+            const int ax_l = ax + lane;                                   // lane l speaks for axis ax + l
+            const int c_l = ax_l == 0 ? cnt3[0] : (ax_l == 1 ? cnt3[1] : cnt3[2]);
+            const double mt_l = c_l >= 1 ? fmin((double)max_trials, dynamic_max_trials(c_l >= 1 ? c_l : 1, n, ms, stop_prob)) : INFINITY;
+            const unsigned long long okm = __ballot(mt_l <= 1.0) & ((1ull << na) - 1ull);   // n_trials_ = 1 >= max_trials: fit() leaves its loop
+            const int n_ok = (okm & 1ull) ? ((okm & 2ull) ? ((okm & 4ull) ? 3 : 2) : 1) : 0;   // leading axes that stop after their first trial
+            PF_ADD(15);
+            const unsigned need_bits = ((1u << n_ok) - 1u) << ax;
+#pragma unroll
+            for (int k = 0; k < PF_TILE; ++k) {
+                const int i = k * 64 + lane;
+                if (k * 64 < n && i < n && (~inl[k] & need_bits) != 0u) kp[r0 + i] &= (uint8_t)~2u;
+            }
+            if (n_ok < na) {                                              // back to where axis ax + n_ok starts
+                const int skip = n_ok > 0 ? sh_end[n_ok - 1] : 0;
+                __syncthreads();
+                for (int i = lane; i < MT_N; i += 64) mt[i] = snap[i];
+                pos_mt = (int)snap[MT_N];
+                __syncthreads();
+                mt_skip(mt, pos_mt, skip, lane);
+            }
+            ax += n_ok;
+            PF_ADD(7);
+#ifdef GSF_PF_TIMING
+            pf_acc[8] += n_ok; pf_acc[11] += 1;
+#endif
+            if (ax >= 3) break;
+          }
+          {
             const double* yp = pos + (r_base + r0) * 3 + ax;
 #pragma unroll
-            for (int k = 0; k < PF_TILE; ++k) { const int i = k * 64 + lane; if (in_regs && k * 64 < n) yv[k] = yp[(int64_t)(i < n ? i : n - 1) * 3]; }
+            for (int k = 0; k < PF_TILE; ++k) yv[k] = ax == 0 ? y3[0][k] : (ax == 1 ? y3[1][k] : y3[2][k]);
             PF_T0();
             for (int i = lane; i <= MT_N; i += 64) snap[i] = (i < MT_N) ? mt[i] : (uint32_t)pos_mt;
             __syncthreads();
@@ -469,7 +552,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             // ~600 dependent instructions of the stream walk.  The walk itself runs redundantly on every lane (wave-uniform state).
             int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0, last_nb = 0;
             double best_score = -INFINITY, max_tr = (double)max_trials;
-            for (int tbn = 4; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
+            for (int tbn = gen.first_batch; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
                 const int nb = (max_trials - drawn < tbn) ? (max_trials - drawn) : tbn;
                 if (nb <= 0) break;
                 if (identity) {
@@ -577,79 +660,116 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
 #pragma unroll
                 for (int k = 0; k < PF_TILE; ++k) {
                     const int i = k * 64 + lane;
-                    if (k * 64 < n && i < n && !(fabs(yv[k] - poly_predict(mb, degree, tv[k])) <= thr)) keep[r_base + r0 + i] &= (uint8_t)~2u;
+                    if (k * 64 < n && i < n && !(fabs(yv[k] - poly_predict(mb, degree, tv[k])) <= thr)) kp[r0 + i] &= (uint8_t)~2u;
                 }
             } else {
                 for (int i = lane; i < n; i += 64) {
                     const bool in = fabs(yp[(int64_t)i * 3] - poly_predict(mb, degree, tp[i])) <= thr;
-                    if (!in) keep[r_base + r0 + i] &= (uint8_t)~2u;
+                    if (!in) kp[r0 + i] &= (uint8_t)~2u;
                 }
             }
             __syncthreads();
             PF_ADD(6);
+          }
         }
+#ifdef GSF_PF_TIMING
+        const long long pf_f0 = clock64();
+#endif
         for (int i = lane; i < n; i += 64) {
-            const uint8_t v = keep[r_base + r0 + i];
-            keep[r_base + r0 + i] = (uint8_t)((v & 1u) | ((wstat == 0 && (v & 2u)) ? 1u : 0u));
+            const uint8_t v = kp[r0 + i];
+            kp[r0 + i] = (uint8_t)((v & 1u) | ((wstat == 0 && (v & 2u)) ? 1u : 0u));
         }
         __syncthreads();
+#ifdef GSF_PF_TIMING
+        pf_acc[18] += clock64() - pf_f0;
+#endif
         return wstat;
     };
     int processed = 0, succeeded = 0;
-    if (gen.mode == 0) {
-        for (int64_t w = win_offsets[b]; w < win_offsets[b + 1]; ++w) {
-            const int ws = run_window(win_rows[w * 2], win_rows[w * 2 + 1]);
-            if (lane == 0) win_status[w] = ws;
-            if (ws == 3) break;
-            processed += ws != 2; succeeded += ws == 0;
-        }
-    } else if (gen.mode == 2) {                                           // ref :148-182: one fit over the whole log; if it raises the log passes unfiltered
-        const int ws = run_window(0, n_log);
-        processed = 1; succeeded = ws == 0;
-        if (ws == 1) { for (int i = lane; i < n_log; i += 64) keep[r_base + i] = 1; }
-    } else {
-        // ref :196-234.  Stamps must be sorted (every window one row range): checked first.
-        const double* tl = t + r_base;
+    // ONE call site of run_window for the three ways the windows come (the lambda is ~70 KB of code: inlined once, not three times):
+    // mode 0 = row ranges fed by the host, mode 2 = the whole log (ref :148-182), mode 1 = the sliding windows of ref :196-234 found here.
+    const double* tl = t + r_base;
+    double t_first = 0.0, t_last = 0.0, w0 = 0.0, w1 = 0.0;
+    const bool log_regs = n_log <= 64 * PF_TILE;
+    double tlv[PF_TILE];                                                  // mode 1, logs of up to 64 x PF_TILE fixes: the stamps sit in registers for the walk
+#pragma unroll
+    for (int k = 0; k < PF_TILE; ++k) tlv[k] = 0.0;
+    if (gen.mode == 1) {
+        // stamps must be sorted (every window one row range): checked first
         bool sorted = true;
         for (int i = lane; i + 1 < n_log; i += 64) sorted = sorted && tl[i] <= tl[i + 1];
         if (__ballot(!sorted) != 0ull) lstat = 3;
         else {
-            const double t_first = tl[0], t_last = tl[n_log - 1];
-            // first row with stamp >= x / > x (wave-parallel count of the rows below: the stamps are sorted)
-            auto rows_below = [&](const double x, const bool strict) -> int {
-                int c = 0;
-                for (int i0 = 0; i0 < n_log; i0 += 64) {
-                    const int i = i0 + lane;
-                    const bool below = i < n_log && (strict ? tl[i] < x : tl[i] <= x);
-                    const int k = __popcll(__ballot(below));
-                    c += k;
-                    if (k < 64) break;
+            t_first = tl[0]; t_last = tl[n_log - 1]; w0 = t_first;
+#pragma unroll
+            for (int k = 0; k < PF_TILE; ++k) { const int i = k * 64 + lane; tlv[k] = (log_regs && k * 64 < n_log) ? tl[i < n_log ? i : n_log - 1] : 0.0; }
+        }
+    }
+    // first row with stamp >= x / > x (wave-parallel count of the rows below: the stamps are sorted)
+    auto rows_below = [&](const double x, const bool strict) -> int {
+        int c = 0;
+        if (log_regs) {
+#pragma unroll
+            for (int k = 0; k < PF_TILE; ++k) {
+                if (k * 64 < n_log) {                                     // wave-uniform
+                    const bool below = (k * 64 + lane < n_log) && (strict ? tlv[k] < x : tlv[k] <= x);
+                    c += __popcll(__ballot(below));
                 }
-                return c;
-            };
-            double w0 = t_first;
-            int visited = 0;
-            while (w0 < t_last) {                                         // :200
-                if (++visited > gen.max_windows) { lstat = 3; break; }
-                const double w1 = w0 + gen.width;                         // :201
-                const int r0 = rows_below(w0, true), r1 = rows_below(w1, true);   // rows with w0 <= t < w1 (:202)
-                if (r1 - r0 >= gen.need) {                                // :204
-                    const int ws = run_window(r0, r1);
-                    if (ws == 3) break;
-                    processed += 1; succeeded += ws == 0;
-                }
-                if (gen.stride <= 1e-6) {                                 // :230-232
-                    const int nx = rows_below(w0, false);                 // first row with t > w0
-                    if (nx < n_log) w0 = tl[nx]; else break;
-                } else w0 += gen.stride;                                  // :233
-                if (w0 >= t_last && t_last >= w1) w0 = fmax(t_first, t_last - gen.width + 1e-6);   // :234-235
             }
+            return c;
+        }
+        for (int i0 = 0; i0 < n_log; i0 += 64) {
+            const int i = i0 + lane;
+            const bool below = i < n_log && (strict ? tl[i] < x : tl[i] <= x);
+            const int k = __popcll(__ballot(below));
+            c += k;
+            if (k < 64) break;
+        }
+        return c;
+    };
+    int64_t w = gen.mode == 0 ? win_offsets[b] : 0;
+    const int64_t w_end = gen.mode == 0 ? win_offsets[b + 1] : 1;
+    int visited = 0;
+    for (;;) {
+        int r0 = 0, r1 = 0;
+        bool run = true;
+        if (gen.mode == 1) {
+            if (lstat == 3 || !(w0 < t_last)) break;                      // :200
+            if (++visited > gen.max_windows) { lstat = 3; break; }
+            w1 = w0 + gen.width;                                          // :201
+            r0 = rows_below(w0, true); r1 = rows_below(w1, true);         // rows with w0 <= t < w1 (:202)
+            run = r1 - r0 >= gen.need;                                    // :204
+        } else {
+            if (w >= w_end) break;
+            if (gen.mode == 0) { r0 = win_rows[w * 2]; r1 = win_rows[w * 2 + 1]; } else { r0 = 0; r1 = n_log; }
+        }
+        int ws = -1;
+        if (run) ws = run_window(r0, r1);
+        if (gen.mode == 0) {
+            if (lane == 0) win_status[w] = ws;
+            if (ws == 3) break;
+            processed += ws != 2; succeeded += ws == 0;
+            ++w;
+        } else if (gen.mode == 2) {                                       // if the one fit raises, the log passes unfiltered
+            processed = 1; succeeded = ws == 0;
+            if (ws == 1) { for (int i = lane; i < n_log; i += 64) kp[i] = 1; }
+            ++w;
+        } else {
+            if (run) {
+                if (ws == 3) break;
+                processed += 1; succeeded += ws == 0;
+            }
+            if (gen.stride <= 1e-6) {                                     // :230-232
+                const int nx = rows_below(w0, false);                     // first row with t > w0
+                if (nx < n_log) w0 = tl[nx]; else break;
+            } else w0 += gen.stride;                                      // :233
+            if (w0 >= t_last && t_last >= w1) w0 = fmax(t_first, t_last - gen.width + 1e-6);   // :234-235
         }
     }
     for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
 #ifdef GSF_PF_TIMING
     pf_acc[10] = clock64() - pf_start;
-    if (lane == 0 && log_info) { for (int k = 0; k < 12; ++k) log_info[b * 16 + k] = (int32_t)(pf_acc[k] > 0x7fffffff ? 0x7fffffff : pf_acc[k]); st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; }
+    if (lane == 0 && log_info) { for (int k = 0; k < 20; ++k) log_info[b * 20 + k] = (int32_t)(pf_acc[k] > 0x7fffffff ? 0x7fffffff : pf_acc[k]); st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; }
     (void)processed; (void)succeeded;
 #else
     if (lane == 0) { st[MT_N] = (uint32_t)pos_mt; log_status[b] = lstat; if (log_info) { log_info[b * 2] = processed; log_info[b * 2 + 1] = succeeded; } }
@@ -727,7 +847,7 @@ int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos
     GSF_REQUIRE(chain_lds(max_trials, min_samples, max_window_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, (const int32_t*)nullptr, win_rows, win_offsets,
                        (int)max_trials, (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status,
-                       WinGen{ 0, min_samples, 0.0, 0.0, 1, 0 }, (int32_t*)nullptr);
+                       WinGen{ 0, min_samples, 0.0, 0.0, 1, 0, ctx->prefilter_first_batch, ctx->prefilter_speculate }, (int32_t*)nullptr);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -747,7 +867,7 @@ int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, 
     int jseq_elems = 0; size_t lds = 0;
     GSF_REQUIRE(chain_lds(f->max_trials, f->min_samples, max_log_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / log length exceed the device sampler's LDS budget");
     const WinGen gen{ f->use_sliding_window ? 1 : 2, f->min_samples, f->window_duration_seconds, f->window_duration_seconds * f->window_step_factor,
-                      f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096 };
+                      f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096, ctx->prefilter_first_batch, ctx->prefilter_speculate };
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, counts, (const int32_t*)nullptr,
                        (const int64_t*)nullptr, (int)f->max_trials, (int)f->min_samples, (int)f->polynomial_degree, f->residual_threshold_meters,
                        f->stop_probability > 0.0 ? f->stop_probability : 0.99, jseq_elems, mt_state, keep, (int32_t*)nullptr, log_status, gen, log_info);
