@@ -70,4 +70,25 @@ __device__ __forceinline__ unsigned long long ransac_key(const long long count, 
     return ((unsigned long long)(count + 1) << 32) | (unsigned long long)(0x7fffffff - trial);
 }
 
+// The final fit on the inliers (ref :420-421) sums two passes of moments.  Both routes that form it -- K2b's block of RANSAC_FINAL_THREADS
+// threads (gsf_sim3.hip: ransac_finish) and the early-exit probe's single wave for a set whose every row is an inlier (gsf_robust.hip) -- add
+// one row at a time with these two functions, thread by thread in the same order, so the sums carry the same bits.
+constexpr int RANSAC_FINAL_THREADS = 256;
+__device__ __forceinline__ void final_moments1(double* acc, const double sx, const double sy, const double sz, const double dx, const double dy, const double dz)
+{
+    acc[0] += 1.0;
+    acc[1] += sx; acc[2] += sy; acc[3] += sz;
+    acc[4] += dx; acc[5] += dy; acc[6] += dz;
+}
+__device__ __forceinline__ void final_moments2(double* h, const double sx, const double sy, const double sz, const double dx, const double dy, const double dz,
+                                               const double* sc, const double* dc)
+{
+    const double a0 = sx - sc[0], a1 = sy - sc[1], a2 = sz - sc[2];
+    const double b0 = dx - dc[0], b1 = dy - dc[1], b2 = dz - dc[2];
+    h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
+    h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
+    h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
+    h[9] += a0 * a0 + a1 * a1 + a2 * a2;
+}
+
 }  // namespace

@@ -14,12 +14,16 @@ using namespace gsf;
 
 namespace {
 
+// (optional, the robust chain: fixed-stride trajectories) the chosen rows compacted into slot [b*N, b*N + n_b) by the same pass that marks them --
+// what compact_valid_kernel does from the mask, without the mask's trip through memory and without its launch
+struct RowsCompact { const double* pos; double* src; double* dst; int32_t* rowmap; int32_t* counts; int64_t* offsets; int64_t B; };
+
 // one wave per trajectory: which rows feed the Sim3 fit, main_process_gui's way (ref :973-998; gsf_set_sim3_rows mode 1,
 // gsf_sim3_fit_rows_batch_dev).  Pass 1 walks the valid rows for the first gap and counts what the duration limit keeps; the
 // reference's two fall-backs are decided from the counts; pass 2 writes the mask.
 __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict__ ts, const double* __restrict__ gps, const uint8_t* __restrict__ valid,
                                                        const int64_t* __restrict__ offsets, int64_t N, FitRows rule, uint8_t* __restrict__ row_mask,
-                                                       int32_t* __restrict__ n_rows, int32_t* __restrict__ status)
+                                                       int32_t* __restrict__ n_rows, int32_t* __restrict__ status, RowsCompact cp)
 {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
@@ -68,17 +72,27 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
         const bool ok = row_ok(i);
         const double t = tsb[i < n ? i : n - 1];
         const bool sel = ok && flag != SIM3_FLAG_FEW_ROWS && i < row_end && (!use_tlim || t <= tlim);
-        total += __popcll(__ballot(sel));
+        const u64 sm = __ballot(sel);
+        if (cp.src && sel) {
+            const int64_t o = base + total + __popcll(sm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            cp.src[o * 3] = cp.pos[(base + i) * 3]; cp.src[o * 3 + 1] = cp.pos[(base + i) * 3 + 1]; cp.src[o * 3 + 2] = cp.pos[(base + i) * 3 + 2];
+            cp.dst[o * 3] = gpsb[i * 3]; cp.dst[o * 3 + 1] = gpsb[i * 3 + 1]; cp.dst[o * 3 + 2] = gpsb[i * 3 + 2];
+            cp.rowmap[o] = (int32_t)i;
+        }
+        total += __popcll(sm);
         if (i < n) row_mask[base + i] = sel ? 1 : 0;
     }
     if (count == -2) {                                                    // all valid rows: still fewer than min_samples -> ValueError (:975)
         count = total;
         if (total < rule.min_samples) {
-            flag = SIM3_FLAG_FEW_ROWS; count = -1;
+            flag = SIM3_FLAG_FEW_ROWS; count = -1; total = 0;
             for (int64_t i = lane; i < n; i += 64) row_mask[base + i] = 0;
         }
     }
-    if (lane == 0) { n_rows[b] = count; if (status) status[b] = flag; }
+    if (lane == 0) {
+        n_rows[b] = count; if (status) status[b] = flag;
+        if (cp.src) { cp.counts[b] = total; cp.offsets[b] = base; if (b == cp.B - 1) cp.offsets[cp.B] = cp.B * N; }
+    }
 }
 
 // one wave per trajectory: stable compaction of the rows with valid, finite GNSS -- or, under the reference's row choice, of the rows
@@ -124,7 +138,8 @@ __global__ __launch_bounds__(64) void compact_valid_kernel(const double* __restr
 // (mt_choice_kernel + K2b from trial `drawn` on, the arg-max key carried over), so data that never saturates costs what it cost before.
 // Counts are formed with the functions K2b forms them with (gsf_ransac.hpp): the decision is the one the full chain takes.
 //   keys[b][2]      arg-max key of the trials scored here (0 = none usable), [1] = 0 (no caller-fed sample can be out of range)
-//   decided[b]      1 when a trial counted every row: R, t, s, mask, n_inliers are final; the generator stops after that trial's ROUND
+//   decided[b]      1 when a trial counted every row: R, t, s, mask, n_inliers are final; the generator stops after that trial's ROUND;
+//                   2 when the final fit was formed here as well (R, t, s, fit status, mask, n_inliers written): K2b skips the set
 //   trial_info[b]   { deciding trial or -1, trials drawn here }
 constexpr int PROBE_ROUND = 8;
 constexpr int PROBE_TILE = 8;       // row iterations of a set held in registers by the probe (64 rows each)
@@ -132,7 +147,9 @@ __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__
                                                           const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts, int max_trials,
                                                           int probe_trials, int ms, double thr, int32_t* sample_idx, int jseq_bytes,
                                                           unsigned long long* __restrict__ keys, int32_t* __restrict__ decided,
-                                                          int32_t* __restrict__ trial_info)
+                                                          int32_t* __restrict__ trial_info, int min_inliers, double* __restrict__ Rout,
+                                                          double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ fit_status,
+                                                          uint8_t* __restrict__ mask_c, int32_t* __restrict__ n_inliers)
 {
     __shared__ uint32_t mt[MT_N + 1];
     extern __shared__ uint16_t jseq[];
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__
     const int n = counts[b];
     const int64_t i0 = offsets[b];
     int32_t* my_idx = sample_idx + (size_t)b * (size_t)max_trials * (size_t)ms;
-    long long best = -1; int best_trial = 0x7fffffff, drawn = 0; bool sat = false;
+    long long best = -1; int best_trial = 0x7fffffff, drawn = 0; bool sat = false, finished = false;
     if (!(n < ms || n < 1 || n > CHOICE_MAX_N)) {                         // else: the reference returns before drawing (ref :395-397), stream untouched
         uint32_t* st = state + b * MT_STATE_WORDS;
         for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
@@ -202,10 +219,67 @@ __global__ __launch_bounds__(64) void robust_probe_kernel(uint32_t* __restrict__
         }
         for (int i = lane; i < MT_N; i += 64) st[i] = mt[i];
         if (lane == 0) st[MT_N] = (uint32_t)pos;
+        // ---- a decided set whose rows sit in registers is finished here: every row is an inlier of the kept trial (mask = all ones, count = n),
+        // and the final fit (ref :420-421) is Umeyama over ALL rows -- what K2b's finishing block would compute after fitting the kept sample
+        // again, marking the rows, and seventeen block reductions (32 us of the 131 us chain at 1 000 x 271; here ~8 us inside a launch that is
+        // waiting for its slowest wave anyway).  The sums follow that block's order: thread v of its 256 adds rows v, v + 256, ... (tiles
+        // k = w, w + 4, ... for the lanes of its wave w), a wave_sum per wave, the four waves added in turn (block_sum, gsf_sim3.hip).
+        if (sat && in_regs && Rout) {
+            finished = true;
+            for (int k = lane; k < n; k += 64) mask_c[i0 + k] = 1;
+            double Ro[9], to[3], so = NAN; int32_t fs = SIM3_NONE;
+            if (n >= min_inliers) {                                       // ref :416-418 (the count is n)
+                constexpr int VW = RANSAC_FINAL_THREADS / 64;
+                double tot[7], H[10];
+                {
+                    double acc[VW][7];
+#pragma unroll
+                    for (int w = 0; w < VW; ++w)
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) acc[w][c] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < PROBE_TILE; ++k)
+                        if (k * 64 + lane < n) final_moments1(acc[k % VW], rx[k][0], rx[k][1], rx[k][2], rx[k][3], rx[k][4], rx[k][5]);
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) {
+                        double r = 0.0;
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) r += wave_sum(acc[w][c]);
+                        tot[c] = r;
+                    }
+                }
+                const double cntf = tot[0];
+                const double sc[3] = { tot[1] / cntf, tot[2] / cntf, tot[3] / cntf }, dc[3] = { tot[4] / cntf, tot[5] / cntf, tot[6] / cntf };
+                {
+                    double h[VW][10];
+#pragma unroll
+                    for (int w = 0; w < VW; ++w)
+#pragma unroll
+                        for (int c = 0; c < 10; ++c) h[w][c] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < PROBE_TILE; ++k)
+                        if (k * 64 + lane < n) final_moments2(h[k % VW], rx[k][0], rx[k][1], rx[k][2], rx[k][3], rx[k][4], rx[k][5], sc, dc);
+#pragma unroll
+                    for (int c = 0; c < 10; ++c) {
+                        double r = 0.0;
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) r += wave_sum(h[w][c]);
+                        H[c] = r;
+                    }
+                }
+                if (cntf >= 3.0) fs = umeyama_finalize(H, H[9], sc, dc, cntf, Ro, to, so);    // every lane, wave-uniform inputs
+            }
+            if (fs == SIM3_NONE) { for (int k = 0; k < 9; ++k) Ro[k] = NAN; to[0] = to[1] = to[2] = NAN; so = NAN; }
+            if (lane == 0) {
+                for (int k = 0; k < 9; ++k) Rout[b * 9 + k] = Ro[k];
+                tout[b * 3] = to[0]; tout[b * 3 + 1] = to[1]; tout[b * 3 + 2] = to[2]; sout[b] = so;
+                fit_status[b] = fs; n_inliers[b] = n;
+            }
+        }
     }
     if (lane == 0) {
         keys[b * 2] = best >= 0 ? ransac_key(best, best_trial) : 0ull; keys[b * 2 + 1] = 0ull;
-        decided[b] = sat ? 1 : 0;
+        decided[b] = sat ? (finished ? 2 : 1) : 0;
         trial_info[b * 2] = sat ? best_trial : -1; trial_info[b * 2 + 1] = drawn;
     }
 }
@@ -280,7 +354,8 @@ namespace gsf {
 int launch_sim3_rows(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
                      const FitRows& rule, uint8_t* row_mask, int32_t* n_rows, int32_t* status)
 {
-    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status);
+    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status,
+                       RowsCompact{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 });
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -315,11 +390,13 @@ extern "C" int gsf_fuse_pipeline_robust_info_batch_dev(gsf_ctx* ctx, const doubl
     int32_t* fit = (int32_t*)(w + o_fit); int32_t* fail = (int32_t*)(w + o_fail); double* ip = (double*)(w + o_ip); double* iq = (double*)(w + o_iq);
     // the rows the fit may draw from: every valid row, or the reference's choice (ref :973-998)
     uint8_t* rowsel = nullptr; int32_t* rows_status = nullptr;
-    if (ctx->fit_rows.mode != 0) {
+    if (ctx->fit_rows.mode != 0) {                                        // row choice and compaction in one launch
         rowsel = (uint8_t*)(w + o_sel); rows_status = (int32_t*)(w + o_rst);
-        if ((rc = launch_sim3_rows(ctx, ts, gps, valid, nullptr, B, N, ctx->fit_rows, rowsel, (int32_t*)(w + o_rn), rows_status))) return rc;
+        hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
+                           (int32_t*)(w + o_rn), rows_status, RowsCompact{ pos, src, dst, rowmap, counts, offsets, B });
+    } else {
+        hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, (const uint8_t*)rowsel, B, N, src, dst, rowmap, counts, offsets);
     }
-    hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, (const uint8_t*)rowsel, B, N, src, dst, rowmap, counts, offsets);
     GSF_HIP(hipGetLastError());
     unsigned long long* keys = (unsigned long long*)(w + o_key);         // arg-max key per trajectory: K2b leaves the winner's trial there (trial_info)
     int32_t* decided = nullptr; int32_t* pinfo = nullptr; int32_t trial0 = 0;
@@ -331,7 +408,7 @@ extern "C" int gsf_fuse_pipeline_robust_info_batch_dev(gsf_ctx* ctx, const doubl
         const int bytes = choice_lds_bytes(N);
         hipLaunchKernelGGL(robust_probe_kernel, dim3((unsigned)B), dim3(64), (size_t)bytes, ctx->stream, mt_state, (const double*)src, (const double*)dst,
                            (const int64_t*)offsets, (const int32_t*)counts, (int)max_trials, (int)trial0, (int)min_samples, residual_threshold, idx, bytes, keys,
-                           decided, pinfo);
+                           decided, pinfo, (int)min_inliers_needed, R, t, s, fit, mask_c, n_inliers);
         GSF_HIP(hipGetLastError());
         // ... then the wide kernels for the rest of the trials of the trajectories that are still undecided
         if ((rc = launch_mt_choice_rest(ctx, mt_state, counts, B, max_trials, trial0, min_samples, idx, (int32_t)N, decided))) return rc;

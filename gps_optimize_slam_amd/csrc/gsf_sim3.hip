@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64) void windows_finalize_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int RANSAC_THREADS = 256;
+constexpr int RANSAC_THREADS = RANSAC_FINAL_THREADS;     // (gsf_ransac.hpp: the early-exit probe reproduces this block's order of summation)
 constexpr int RANSAC_SPLIT_MAX_SETS = 32;   // up to this many sets, a set's hypotheses go to many single-wave blocks (ransac_scan_kernel)
 constexpr int RANSAC_MAX_SAMPLES = 4096;    // the kernel walks a sample set row by row: no structural limit (a sanity bound)
 
@@ -712,9 +712,7 @@ __device__ __forceinline__ void ransac_finish(int64_t b, unsigned long long key,
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
     for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) {
         if (!inlier_mask[i]) continue;
-        acc[0] += 1.0;
-        acc[1] += src[i * 3]; acc[2] += src[i * 3 + 1]; acc[3] += src[i * 3 + 2];
-        acc[4] += dst[i * 3]; acc[5] += dst[i * 3 + 1]; acc[6] += dst[i * 3 + 2];
+        final_moments1(acc, src[i * 3], src[i * 3 + 1], src[i * 3 + 2], dst[i * 3], dst[i * 3 + 1], dst[i * 3 + 2]);
     }
     double tot[7];
 #pragma unroll
@@ -724,12 +722,7 @@ __device__ __forceinline__ void ransac_finish(int64_t b, unsigned long long key,
     double h[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) {
         if (!inlier_mask[i]) continue;
-        const double a0 = src[i * 3] - sc[0], a1 = src[i * 3 + 1] - sc[1], a2 = src[i * 3 + 2] - sc[2];
-        const double b0 = dst[i * 3] - dc[0], b1 = dst[i * 3 + 1] - dc[1], b2 = dst[i * 3 + 2] - dc[2];
-        h[0] += a0 * b0; h[1] += a0 * b1; h[2] += a0 * b2;
-        h[3] += a1 * b0; h[4] += a1 * b1; h[5] += a1 * b2;
-        h[6] += a2 * b0; h[7] += a2 * b1; h[8] += a2 * b2;
-        h[9] += a0 * a0 + a1 * a1 + a2 * a2;
+        final_moments2(h, src[i * 3], src[i * 3 + 1], src[i * 3 + 2], dst[i * 3], dst[i * 3 + 1], dst[i * 3 + 2], sc, dc);
     }
     double H[10];
 #pragma unroll
@@ -758,6 +751,7 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_batch_kernel(
     __shared__ double sh_red[RANSAC_THREADS / 64];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
+    if (decided && decided[b] == 2) return;                                  // the early-exit probe also formed the final fit: R, t, s, mask, counts are written
     // set b = rows offsets[b] .. offsets[b] + n; n = counts[b] when the sets sit in fixed-stride slots (robust pipeline), else the gap
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
     if (n < ms) {                                                            // ref :395-397
@@ -823,12 +817,13 @@ __global__ __launch_bounds__(RANSAC_THREADS) void ransac_finish_kernel(
     const double* __restrict__ src, const double* __restrict__ dst, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ sample_idx, int trials, int ms, double thr, int min_inliers, const unsigned long long* __restrict__ keys,
     double* __restrict__ Rout, double* __restrict__ tout, double* __restrict__ sout, int32_t* __restrict__ status,
-    uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_inliers)
+    uint8_t* __restrict__ inlier_mask, int32_t* __restrict__ n_inliers, const int32_t* __restrict__ decided)
 {
     __shared__ double sh_fit[13];
     __shared__ double sh_red[RANSAC_THREADS / 64];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
+    if (decided && decided[b] == 2) return;                                  // finished by the early-exit probe
     const int64_t i0 = offsets[b], n = counts ? (int64_t)counts[b] : offsets[b + 1] - offsets[b], i1 = i0 + n;
     if (n < ms) {                                                            // ref :395-397
         for (int64_t i = i0 + tid; i < i1; i += RANSAC_THREADS) inlier_mask[i] = 0;
@@ -974,7 +969,7 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
         hipLaunchKernelGGL(ransac_scan_kernel, dim3((unsigned)((trials - trial0 + 63) / 64), (unsigned)B), dim3(64), 0, ctx->stream, src, dst, offsets, counts,
                            sample_idx, (int)trials, (int)min_samples, thr, keys, frows, ridx, fhdr, total_rows, (int)trial0, decided);
         hipLaunchKernelGGL(ransac_finish_kernel, dim3((unsigned)B), dim3(RANSAC_THREADS), 0, ctx->stream, src, dst, offsets, counts, sample_idx,
-                           (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers);
+                           (int)trials, (int)min_samples, thr, (int)min_inliers, keys, R, t, s, status, inlier_mask, n_inliers, decided);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
     }
