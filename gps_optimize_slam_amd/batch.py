@@ -156,6 +156,16 @@ class GeodeticBatch:
         return cls(B, N, ts, pos, quat, offs, gps_t, gps_llh, mx)
 
 
+    def with_outliers(self, share, metres=40.0, seed=7):
+        """A copy of the batch whose GNSS log has `share` of its fixes pushed `metres` north (multipath-like jumps the pre-filter is there
+        for, ref :136-247); deterministic in `seed`.  SLAM side shared, log copied."""
+        g = torch.Generator(device="cpu"); g.manual_seed(int(seed))
+        hit = (torch.rand(self.gps_t.numel(), generator=g) < float(share)).to(self.gps_llh.device)
+        llh = self.gps_llh.clone()
+        llh[:, 0] += hit.double() * (float(metres) / 111320.0)
+        return GeodeticBatch(self.B, self.N, self.ts, self.pos, self.quat, self.gps_offsets, self.gps_t, llh, self.max_fixes)
+
+
 FIT_ROWS_DEFAULT = "reference"
 
 

@@ -170,10 +170,17 @@ GSF_API int gsf_trim(gsf_ctx *ctx);
                       ends where np.random ends after compute_sim3_transform_robust (EKFGPSSLAM.py:404-405) / 1: a trajectory stops at
                       the first trial that counts every row of its fit -- :413 keeps a trial only on a STRICTLY larger count, so no later
                       trial can change the mask, the count or the final fit; outputs identical bit for bit, GSF_SIM3_FLAG_SATURATED in the
-                      status word, the generator left after the round of eight trials that held the deciding one.  Trajectories that never saturate (one GNSS outlier beyond the threshold is enough) run all
-                      max_trials as before.  The Python batch binding switches it ON, the single-track drop-in never uses it
+                      status word, the generator left after the round of eight trials that held the deciding one.  A trajectory that
+                      never saturates (one GNSS outlier beyond the threshold among its rows is enough) runs all max_trials as before.
+                      The Python batch binding switches it ON, the single-track drop-in never uses it
      "ransac_probe_trials"  (default 64) how many trials the early-exit probe draws and scores per trajectory (one wave each) before
                       the wide kernels take the rest of an undecided trajectory's trials
+     "prefilter_speculate"  1 (default): the GPS pre-filter chain (gsf_gps_prefilter_chain_*, gsf_gps_prefilter_auto_dev, the whole-run entries)
+                      first tries "every axis of the window stops after its first trial" -- three consecutive trials drawn, fitted and
+                      counted at once; an axis whose first trial does not end RANSACRegressor's loop goes through the sequential walk
+                      from the stream position where it starts.  0: the sequential walk only.  Same kept rows, same generator state.
+     "prefilter_first_batch"  (default 1, 1..64) trials the sequential walk draws and scores before its first look at scikit-learn's
+                      stopping rule (the batches then double); any value gives the same words, clean logs are fastest with 1
      "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift
      "ekf_variant"    reserved (0) */
 GSF_API int gsf_set_option(gsf_ctx *ctx, const char *key, int64_t value);

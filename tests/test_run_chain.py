@@ -334,3 +334,52 @@ def test_device_window_walk_equals_the_host_walk(B):
         nwin = torch.as_tensor(np.diff(np.array(wo))).cuda().to(torch.int32)
         assert torch.equal(info[ok, 0], nwin[ok]), (width, factor)
         assert (st_a != B.mt19937_seed(seeds)).any(dim=1).sum() >= nl // 2                      # the logs really drew
+
+
+@pytest.mark.gpu
+def test_prefilter_speculative_pass_and_batch_size_change_no_word(B):
+    """gsf_set_option "prefilter_speculate" / "prefilter_first_batch" only change how many trials the pre-filter chain draws AHEAD of
+    scikit-learn's walk (three axes' first trials at once; a first batch of 1 / 4 / 16 trials): the walk over the trials is the sequential
+    one, in order, so kept rows, log status, windows processed / succeeded and the generator state are the same words -- on logs where
+    most windows stop after one trial (clean stretches), on logs where a third of the windows need several (5 % of the fixes 40 m off on
+    one axis, so the speculative pass misses at the second axis and re-speculates for the third), and on logs where most do (15 %), with
+    windows longer than the register tile (20 Hz: 300 rows) in the mix."""
+    import torch
+    from gps_optimize_slam_amd import _lib
+    from gps_optimize_slam_amd import ekfgpsslam as E
+    L, ctx = _lib.load(), B.context()
+    rng = np.random.default_rng(5)
+    f = dict(E.CONFIG["gps_filtering_ransac"])
+    logs = []
+    for b in range(96):
+        rate = 20.0 if b % 8 == 0 else 10.0
+        n = int(rng.integers(40, 700 if rate > 10 else 400))
+        t = np.arange(n) / rate + rng.uniform(0, 50)
+        p = np.column_stack((3.0 * t + rng.normal(size=n) * 0.2, -2.0 * t + 0.02 * t * t + rng.normal(size=n) * 0.2, 100 + rng.normal(size=n) * 0.2))
+        share = (0.0, 0.05, 0.15)[b % 3]
+        hit = rng.random(n) < share
+        p[hit, 1] += 40.0
+        logs.append((t, p))
+    offs = np.zeros(len(logs) + 1, dtype=np.int64); offs[1:] = np.cumsum([len(t) for t, _ in logs])
+    T = torch.as_tensor(np.concatenate([t for t, _ in logs])).cuda(); P = torch.as_tensor(np.concatenate([p for _, p in logs])).cuda()
+    O = torch.as_tensor(offs).cuda()
+    mx, nl = int(max(len(t) for t, _ in logs)), len(logs)
+    pc = _lib.PrefilterConfig.from_config(f)
+    outs = {}
+    try:
+        for spec, fb in ((0, 1), (0, 4), (0, 16), (1, 1), (1, 4)):
+            ctx.set_option("prefilter_speculate", spec); ctx.set_option("prefilter_first_batch", fb)
+            st = B.mt19937_seed(np.arange(nl) + 77)
+            keep = torch.empty(int(offs[-1]), dtype=torch.uint8, device="cuda"); ls = torch.empty(nl, dtype=torch.int32, device="cuda")
+            info = torch.empty((nl, 2), dtype=torch.int32, device="cuda")
+            _lib.check(L.gsf_gps_prefilter_auto_dev(ctx.handle, B._p(T), B._p(P), B._p(O), nl, mx, C.byref(pc), B._p(st), B._p(keep), B._p(ls), B._p(info)))
+            outs[(spec, fb)] = (keep, ls, info, st)
+    finally:
+        ctx.set_option("prefilter_speculate", 1); ctx.set_option("prefilter_first_batch", 1)
+    ref = outs[(0, 1)]
+    assert (ref[1] == 0).all() and (ref[2][:, 0] > 0).all()
+    kept = ref[0].double().mean().item()
+    assert 0.85 < kept < 0.99                                              # fixes were dropped, most were kept
+    for key, cur in outs.items():
+        for a, b_ in zip(ref, cur):
+            assert torch.equal(a, b_), key

@@ -10,7 +10,7 @@ d = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_default_under_r
 r, r8, c, c5, fc = e["robust_chain_c2"], e["robust_chain_8192"], e["c1_drop_in"], e["c5_shard_1gpu"], e["full_chain_c2"]
 hp = e.get("host_pointer_entry", {})
 hist = ", ".join(f"{v} after {k}" for k, v in r["trials_drawn_by_saturated_trajectories_histogram"].items())
-sp = fc["stage_split"]
+sp = fc["stage_split"]; fo = fc.get("with_2pct_outlier_fixes", {})
 rf = c.get("reference_cpu_ms", {})
 new = f"""{BEGIN}
 * **Headline** (`value`): C2 1 000 × 271, fused pipeline on the reference's Sim3 rows, {d['steps']} graph-replayed steps: {d['ms_per_step'] * 1e3:.2f} µs per step =
@@ -23,7 +23,8 @@ new = f"""{BEGIN}
   ({r['draws_wall_us_per_trial_of_every_stream']:.2f} µs of wall time per trial with every stream drawing in parallel = {r['draws_wall_ns_per_stream_and_trial']:.2f} ns per stream and trial).
 * **Steps 1–6 as one chain, 1 000 × 271** (`full_chain_c2`, {fc['gnss_fixes']:,} fixes): **{fc['ms']:.2f} ms** = {fc['poses_per_s'] / 1e6:.0f} M poses/s with the early exit, {fc['all_trials_ms']:.2f} ms without; stages on their own:
   geodesy slice {sp['geodesy_slice_ms'] * 1e3:.0f} µs, pre-filter {sp['prefilter_ms'] * 1e3:.0f} µs, alignment {sp['time_alignment_ms'] * 1e3:.0f} µs, robust steps 3–5 {sp['robust_steps_3_to_5_ms'] * 1e3:.0f} µs, apply {sp['apply_sim3_all_poses_ms'] * 1e3:.0f} µs, metric of three tracks
-  {sp['error_metric_3_tracks_ms'] * 1e3:.0f} µs; step-6 RMSE (mean over the batch) Sim3 {fc['step6_rmse_m_mean']['sim3']:.2f} m → EKF {fc['step6_rmse_m_mean']['ekf']:.2f} m.  The reference's Python takes ≈ {rf.get('steps_2_to_5', float('nan')):.0f} ms for steps 2–5 of ONE such track.
+  {sp['error_metric_3_tracks_ms'] * 1e3:.0f} µs; step-6 RMSE (mean over the batch) Sim3 {fc['step6_rmse_m_mean']['sim3']:.2f} m → EKF {fc['step6_rmse_m_mean']['ekf']:.2f} m.  With 2 % of the fixes thrown 40 m off
+  (the pre-filter drops them: {fo.get('fixes_kept_share', float('nan')) * 100:.1f} % kept, its windows need more than one trial): {fo.get('ms', float('nan')):.2f} ms.  The reference's Python takes ≈ {rf.get('steps_2_to_5', float('nan')):.0f} ms for steps 2–5 of ONE such track.
 * Chain from the geodetic log with the plain fit (K1 → align → pipeline) {e['geodetic_chain_c2']['ms'] * 1e3:.0f} µs; C2 in the time-major layout (two fused transposes + pipeline) {e['c2_time_major_pipeline_ms'] * 1e3:.0f} µs.
 * **C1 drop-in** (271 poses, warm): GPS leg {c['gps_projection_and_prefilter_ms']['best']:.2f} ms + steps 2–5 {c['steps_2_to_5_ms']['best']:.2f} ms + metric {c['step_6_error_metric_ms']['best']:.2f} ms = **{c['end_to_end_ms']['best']:.2f} ms** end to end; the reference itself:
   steps 2–5 {rf.get('steps_2_to_5', float('nan')):.0f} ms, of it the robust fit {rf.get('compute_sim3_transform_robust', float('nan')):.0f} ms, `apply_ekf_correction` {rf.get('apply_ekf_correction', float('nan')):.0f} ms ({rf.get('source', '?')}).
