@@ -29,8 +29,11 @@ typedef PolyModelT<RP_MAX_DEGREE> PolyModel;
 template <int MAXD>
 __device__ __forceinline__ double poly_predict(const PolyModelT<MAXD>& m, int degree, double t)
 {
+    // (compile-time bounds: a loop to the run-time degree indexes m.coef dynamically, which put every model of the chain kernel into scratch
+    // memory -- each prediction then started with dependent trips to it.  The terms k < degree are formed exactly as that loop formed them.)
     double acc = 0.0, tk = t;
-    for (int k = 0; k < degree; ++k) { acc += m.coef[k] * tk; tk *= t; }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) { acc = (k < degree) ? (acc + m.coef[k] * tk) : acc; tk *= t; }
     return acc + m.intercept;
 }
 
