@@ -342,7 +342,7 @@ def test_prefilter_speculative_pass_and_batch_size_change_no_word(B):
     scikit-learn's walk (three axes' first trials at once; a first batch of 1 / 4 / 16 trials): the walk over the trials is the sequential
     one, in order, so kept rows, log status, windows processed / succeeded and the generator state are the same words -- on logs where
     most windows stop after one trial (clean stretches), on logs where a third of the windows need several (5 % of the fixes 40 m off on
-    one axis, so the speculative pass misses at the second axis and re-speculates for the third), and on logs where most do (15 %), with
+    one axis -- east, north or up from log to log, so the speculative pass misses at the first, second or third axis and re-speculates for what is left), and on logs where most do (15 %), with
     windows longer than the register tile (20 Hz: 300 rows) in the mix."""
     import torch
     from gps_optimize_slam_amd import _lib
@@ -358,7 +358,7 @@ def test_prefilter_speculative_pass_and_batch_size_change_no_word(B):
         p = np.column_stack((3.0 * t + rng.normal(size=n) * 0.2, -2.0 * t + 0.02 * t * t + rng.normal(size=n) * 0.2, 100 + rng.normal(size=n) * 0.2))
         share = (0.0, 0.05, 0.15)[b % 3]
         hit = rng.random(n) < share
-        p[hit, 1] += 40.0
+        p[hit, (b // 3) % 3] += 40.0                                      # the axis that misses differs from log to log: every re-speculation path runs
         logs.append((t, p))
     offs = np.zeros(len(logs) + 1, dtype=np.int64); offs[1:] = np.cumsum([len(t) for t, _ in logs])
     T = torch.as_tensor(np.concatenate([t for t, _ in logs])).cuda(); P = torch.as_tensor(np.concatenate([p for _, p in logs])).cuda()
