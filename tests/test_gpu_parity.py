@@ -743,6 +743,42 @@ def test_error_metric_kernel_vs_reference(E, golden, tag):
         assert np.isnan(r["errors"][~post]).all() and np.isfinite(r["errors"][post]).all()
 
 
+@pytest.mark.parametrize("N", [5, 30, 64, 65, 130, 271, 400, 700, 1000, 1536, 1700])
+def test_error_metric_kernel_every_tile_shape(B, N):
+    """eval_errors_lds_kernel spreads the M x M pair work (nearest fix, :1030-1031; rank count of the median, :1033) as a register tile of
+    1 .. 8 queries per thread over S = 1 .. 64 lanes per query -- one template instance per tile length: track lengths that reach every
+    instance (M * S / 256 = 1 .. 8 passes, S from 64 down to 1), N = 1 700 beyond the LDS kernel (one thread per query), tracks with no,
+    one and two evaluated poses, duplicated errors (the tie rule of the rank count) -- against NumPy's cdist-min / mean / median / RMSE of
+    the same rows.  (The three-tracks-per-launch form runs in tests/test_run_chain.py against the goldens' step-6 rows.)"""
+    import torch
+    rng = np.random.default_rng(N)
+    nb = 12
+    ts = np.cumsum(rng.uniform(0.05, 0.15, size=(nb, N)), axis=1)
+    p = np.cumsum(rng.normal(size=(nb, N, 3)), axis=1)
+    g = p + rng.normal(size=(nb, N, 3)) * 0.5
+    valid = (rng.random((nb, N)) < 0.8).astype(np.uint8)
+    valid[0] = 0                                                            # nothing to evaluate
+    valid[1] = 0; valid[1, N - 1] = 1                                       # one pose
+    valid[2] = 0; valid[2, N - 1] = 1; valid[2, N - 2] = 1                  # two poses
+    p[3] = 0.0; p[3, :, 0] = 100.0 * np.arange(N); g[3] = p[3] + np.array([3.0, 0.0, 4.0])   # every error exactly 5: ranks decided by the row order alone
+    g[4, ::7] = np.nan                                                      # NaN fixes leave the set (:1016)
+    skip = 0.5
+    T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+    stats, err = B.eval_errors_batch(T(ts), T(p), T(g), T(valid, torch.uint8), skip)
+    stats, err = stats.cpu().numpy(), err.cpu().numpy()
+    for b in range(nb):
+        sel = (valid[b] != 0) & (ts[b] > ts[b, 0] + skip) & np.isfinite(g[b]).all(axis=1)
+        assert stats[b, 0] == sel.sum() and np.isnan(err[b][~sel]).all()
+        if not sel.any():
+            assert np.isnan(stats[b, 1:]).all()
+            continue
+        d = np.sqrt(((p[b][sel][:, None, :] - g[b][sel][None, :, :]) ** 2).sum(axis=2)).min(axis=1)
+        np.testing.assert_allclose(err[b][sel], d, atol=1e-9, rtol=0)
+        np.testing.assert_allclose(stats[b, 1:], [d.mean(), np.median(d), np.sqrt((d ** 2).mean())], atol=1e-9, rtol=0)
+        assert stats[b, 2] == np.median(err[b][sel])                         # the median is an order statistic of the kernel's own errors: exact
+    assert (err[3][np.isfinite(err[3])] == 5.0).all()
+
+
 def test_run_fusion_headless_driver(E, golden, tmp_path):
     """Steps 1-7 of main_process_gui without the GUI, file in / file out, on a copy of the bundled-shaped data."""
     g, k = golden("c1_combined.npz"), golden("kat_bundled.npz")
