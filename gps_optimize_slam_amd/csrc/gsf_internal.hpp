@@ -112,6 +112,8 @@ int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, 
                               int32_t max_log_rows, const gsf_prefilter_config* f, uint32_t* mt_state, uint8_t* keep, int32_t* log_status, int32_t* log_info);
 
 // step 6 for raw SLAM / Sim3 / EKF in one launch (gsf_eval.hip): stats[3][B][4], errors[3][B][N]
+int launch_apply_sim3(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R, const double* t,
+                      const double* s, double* pos_out, double* quat_out, int32_t* bad_quat, bool bad_quat_zeroed);
 int launch_eval_errors3(gsf_ctx* ctx, const double* ts, const double* traj0, const double* traj1, const double* traj2, const double* aligned_gps,
                         const uint8_t* valid, int64_t B, int64_t N, double skip_seconds, double* stats, double* errors);
 

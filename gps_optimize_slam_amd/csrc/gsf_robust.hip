@@ -21,6 +21,11 @@ struct RowsCompact { const double* pos; double* src; double* dst; int32_t* rowma
 // one wave per trajectory: which rows feed the Sim3 fit, main_process_gui's way (ref :973-998; gsf_set_sim3_rows mode 1,
 // gsf_sim3_fit_rows_batch_dev).  Pass 1 walks the valid rows for the first gap and counts what the duration limit keeps; the
 // reference's two fall-backs are decided from the counts; pass 2 writes the mask.
+// TILE: the trajectory's rows (stamp, fix, valid byte) are fetched ONCE into registers -- up to 64 x ROWS_TILE = 512 poses, every load in flight
+// together -- and both passes run from there; the loop form makes three to five dependent trips to memory per pass (a lone wave per
+// trajectory: each trip is ~0.7 us).  Same chunks, same order, same helper: the same words.
+constexpr int ROWS_TILE = 8;
+template <bool TILE>
 __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict__ ts, const double* __restrict__ gps, const uint8_t* __restrict__ valid,
                                                        const int64_t* __restrict__ offsets, int64_t N, FitRows rule, uint8_t* __restrict__ row_mask,
                                                        int32_t* __restrict__ n_rows, int32_t* __restrict__ status, RowsCompact cp)
@@ -36,17 +41,25 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
         if (gpsb) ok = ok && !(isnan(gpsb[i * 3]) || isnan(gpsb[i * 3 + 1]) || isnan(gpsb[i * 3 + 2]));
         return ok;
     };
+    // TILE (launcher: gps != NULL, n <= 64 * ROWS_TILE): row k * 64 + lane
+    double tt[ROWS_TILE], gx[ROWS_TILE], gy[ROWS_TILE], gz[ROWS_TILE];
+    bool okk[ROWS_TILE];
+    if (TILE) {
+#pragma unroll
+        for (int k = 0; k < ROWS_TILE; ++k) {
+            const int64_t i = (int64_t)k * 64 + lane, ic = i < n ? i : n - 1;
+            tt[k] = tsb[ic]; gx[k] = gpsb[ic * 3]; gy[k] = gpsb[ic * 3 + 1]; gz[k] = gpsb[ic * 3 + 2];
+            okk[k] = i < n && valb[ic] != 0 && !(isnan(gx[k]) || isnan(gy[k]) || isnan(gz[k]));
+        }
+    }
     RowScan rs{ false, 0.0, 0, 0 };
     bool gap_found = false, have_t0 = false, carry_in_T = false;
     int row_end = (int)n;
     int nF = 0, nT = 0;
     double tlim = 0.0;
-    for (int64_t c0 = 0; c0 < n && !gap_found; c0 += 64) {
-        const int64_t i = c0 + lane;
-        const bool ok = row_ok(i);
-        const double t = tsb[i < n ? i : n - 1];
+    auto pass1 = [&](const int64_t c0, const bool ok, const double t) __attribute__((always_inline)) {
         const u64 m = __ballot(ok);
-        if (m == 0ull) continue;
+        if (m == 0ull) return;
         if (!have_t0) { tlim = lane_bcast(t, __ffsll((long long)m) - 1) + rule.max_dur; have_t0 = true; }   // segment_start_time + max_dur (:988-990)
         bool in_chunk = false;
         gap_found = rows_gap_in_chunk(rs, m, t, ok, lane, (int)c0, rule.max_gap, row_end, nF, in_chunk);
@@ -58,6 +71,16 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
             nT += __popcll(tm);
             carry_in_T = ((tm >> (63 - __clzll((long long)m))) & 1ull) != 0ull;
         }
+    };
+    if (TILE) {
+#pragma unroll
+        for (int k = 0; k < ROWS_TILE; ++k)
+            if ((int64_t)k * 64 < n && !gap_found) pass1((int64_t)k * 64, okk[k], tt[k]);
+    } else {
+        for (int64_t c0 = 0; c0 < n && !gap_found; c0 += 64) {
+            const int64_t i = c0 + lane;
+            pass1(c0, row_ok(i), tsb[i < n ? i : n - 1]);
+        }
     }
     if (!gap_found) nF = rs.nvalid;
     bool use_tlim = true;
@@ -67,20 +90,31 @@ __global__ __launch_bounds__(64) void sim3_rows_kernel(const double* __restrict_
         else { row_end = (int)n; use_tlim = false; flag = SIM3_FLAG_ROWS_ALL; count = -2; }   // :984 (counted in pass 2)
     } else if (nT < rule.min_samples) { use_tlim = false; flag = SIM3_FLAG_ROWS_SEGMENT; count = nF; }   // :993-995
     int total = 0;
-    for (int64_t c0 = 0; c0 < n; c0 += 64) {
+    auto pass2 = [&](const int64_t c0, const bool ok, const double t, const double z0, const double z1, const double z2) __attribute__((always_inline)) {
         const int64_t i = c0 + lane;
-        const bool ok = row_ok(i);
-        const double t = tsb[i < n ? i : n - 1];
         const bool sel = ok && flag != SIM3_FLAG_FEW_ROWS && i < row_end && (!use_tlim || t <= tlim);
         const u64 sm = __ballot(sel);
         if (cp.src && sel) {
             const int64_t o = base + total + __popcll(sm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
             cp.src[o * 3] = cp.pos[(base + i) * 3]; cp.src[o * 3 + 1] = cp.pos[(base + i) * 3 + 1]; cp.src[o * 3 + 2] = cp.pos[(base + i) * 3 + 2];
-            cp.dst[o * 3] = gpsb[i * 3]; cp.dst[o * 3 + 1] = gpsb[i * 3 + 1]; cp.dst[o * 3 + 2] = gpsb[i * 3 + 2];
+            cp.dst[o * 3] = z0; cp.dst[o * 3 + 1] = z1; cp.dst[o * 3 + 2] = z2;
             cp.rowmap[o] = (int32_t)i;
         }
         total += __popcll(sm);
         if (i < n) row_mask[base + i] = sel ? 1 : 0;
+    };
+    if (TILE) {
+#pragma unroll
+        for (int k = 0; k < ROWS_TILE; ++k)
+            if ((int64_t)k * 64 < n) pass2((int64_t)k * 64, okk[k], tt[k], gx[k], gy[k], gz[k]);
+    } else {
+        for (int64_t c0 = 0; c0 < n; c0 += 64) {
+            const int64_t i = c0 + lane;
+            const bool ok = row_ok(i);
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            if (cp.src && ok) { z0 = gpsb[i * 3]; z1 = gpsb[i * 3 + 1]; z2 = gpsb[i * 3 + 2]; }
+            pass2(c0, ok, tsb[i < n ? i : n - 1], z0, z1, z2);
+        }
     }
     if (count == -2) {                                                    // all valid rows: still fewer than min_samples -> ValueError (:975)
         count = total;
@@ -354,8 +388,11 @@ namespace gsf {
 int launch_sim3_rows(gsf_ctx* ctx, const double* ts, const double* gps, const uint8_t* valid, const int64_t* offsets, int64_t B, int64_t N,
                      const FitRows& rule, uint8_t* row_mask, int32_t* n_rows, int32_t* status)
 {
-    hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status,
-                       RowsCompact{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 });
+    const RowsCompact none{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+    if (!offsets && gps && N <= 64 * ROWS_TILE)
+        hipLaunchKernelGGL(sim3_rows_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status, none);
+    else
+        hipLaunchKernelGGL(sim3_rows_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, offsets, N, rule, row_mask, n_rows, status, none);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -392,8 +429,13 @@ extern "C" int gsf_fuse_pipeline_robust_info_batch_dev(gsf_ctx* ctx, const doubl
     uint8_t* rowsel = nullptr; int32_t* rows_status = nullptr;
     if (ctx->fit_rows.mode != 0) {                                        // row choice and compaction in one launch
         rowsel = (uint8_t*)(w + o_sel); rows_status = (int32_t*)(w + o_rst);
-        hipLaunchKernelGGL(sim3_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
-                           (int32_t*)(w + o_rn), rows_status, RowsCompact{ pos, src, dst, rowmap, counts, offsets, B });
+        const RowsCompact cp{ pos, src, dst, rowmap, counts, offsets, B };
+        if (N <= 64 * ROWS_TILE)
+            hipLaunchKernelGGL(sim3_rows_kernel<true>, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
+                               (int32_t*)(w + o_rn), rows_status, cp);
+        else
+            hipLaunchKernelGGL(sim3_rows_kernel<false>, dim3((unsigned)B), dim3(64), 0, ctx->stream, ts, gps, valid, (const int64_t*)nullptr, N, ctx->fit_rows, rowsel,
+                               (int32_t*)(w + o_rn), rows_status, cp);
     } else {
         hipLaunchKernelGGL(compact_valid_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, pos, gps, valid, (const uint8_t*)rowsel, B, N, src, dst, rowmap, counts, offsets);
     }

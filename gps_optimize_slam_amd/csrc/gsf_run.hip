@@ -15,12 +15,6 @@ using namespace gsf;
 
 namespace {
 
-__global__ void run_offsets_kernel(int64_t* off, int64_t B, int64_t N)
-{
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= B) off[b] = b * N;
-}
-
 // one wave per log: stable compaction of the fixes the loader keeps (ref :259-264: the geodesy slice marks a dropped fix by NaN easting AND
 // northing) into slot [gps_offsets[b], +counts[b]); rowmap = the row of the log each slot came from
 __global__ __launch_bounds__(64) void run_compact_rows_kernel(const double* __restrict__ gps_t, const double* __restrict__ utm, const int64_t* __restrict__ offsets,
@@ -51,10 +45,13 @@ __global__ __launch_bounds__(64) void run_compact_rows_kernel(const double* __re
 __global__ __launch_bounds__(64) void run_filtered_rows_kernel(const double* __restrict__ utm, const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts,
                                                                const int32_t* __restrict__ rowmap, const uint8_t* __restrict__ ckeep,
                                                                const int32_t* __restrict__ log_status, double* __restrict__ fut,
-                                                               uint8_t* __restrict__ gps_keep, int32_t* __restrict__ run_status)
+                                                               uint8_t* __restrict__ gps_keep, int32_t* __restrict__ run_status,
+                                                               int64_t* __restrict__ slam_off, int32_t* __restrict__ bad_quat, int64_t B, int64_t N)
 {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x, base = offsets[b], n_log = offsets[b + 1] - base;
+    // (two chores of the later steps ride along: the fixed-stride offsets of the SLAM tracks, and the zeroed flag K3 ORs into)
+    if (lane == 0) { slam_off[b] = b * N; if (b == B - 1) slam_off[B] = B * N; bad_quat[b] = 0; }
     const int n = counts[b];
     const bool unhandled = log_status[b] != 0;
     for (int64_t i = lane; i < n_log; i += 64) {
@@ -143,11 +140,9 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     GSF_HIP(hipGetLastError());
     if ((rc = launch_gps_prefilter_auto(ctx, ct, cp, gps_offsets, counts, B, max_fixes > 0 ? max_fixes : 1, &cfg->gps_filter, mt_state, ckeep, log_status, log_info))) return rc;
     hipLaunchKernelGGL(run_filtered_rows_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, (const double*)gps_utm, gps_offsets, (const int32_t*)counts,
-                       (const int32_t*)rowmap, (const uint8_t*)ckeep, (const int32_t*)log_status, fut, gps_keep, run_status);
+                       (const int32_t*)rowmap, (const uint8_t*)ckeep, (const int32_t*)log_status, fut, gps_keep, run_status, slam_off, badq, B, N);
     GSF_HIP(hipGetLastError());
     // ---- step 2
-    hipLaunchKernelGGL(run_offsets_kernel, dim3((unsigned)((B + 256) / 256)), dim3(256), 0, ctx->stream, slam_off, B, N);
-    GSF_HIP(hipGetLastError());
     if ((rc = gsf_time_align_loaded_rows_batch_dev(ctx, ts, slam_off, gps_t, fut, gps_offsets, B, max_fixes > 2 ? max_fixes : 2, cfg->max_gps_gap_threshold,
                                                    aligned, valid, align_status))) return rc;
     // ---- steps 3-5 on the rows main_process_gui picks (ref :973-998), whatever the context's own row rule is
@@ -159,7 +154,7 @@ extern "C" int gsf_run_fusion_batch_dev(gsf_ctx* ctx, const double* ts, const do
     ctx->fit_rows = saved;
     if (rc) return rc;
     // ---- step 4 for every pose, step 6
-    if ((rc = gsf_apply_sim3_batch_dev(ctx, pos, quat, slam_off, B, R, t, s, sp, sq, badq))) return rc;
+    if ((rc = launch_apply_sim3(ctx, pos, quat, slam_off, B, R, t, s, sp, sq, badq, true))) return rc;
     if ((rc = launch_eval_errors3(ctx, ts, pos, sp, pos_out, aligned, valid, B, N, cfg->eval_skip_seconds, err_stats, errs))) return rc;
     hipLaunchKernelGGL(run_outcome_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, B, N, (const int32_t*)status, run_status, R, t, s, pos_out, quat_out,
                        sim3_pos, err_stats, n_inliers, (const int32_t*)badq);

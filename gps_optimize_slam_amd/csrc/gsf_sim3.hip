@@ -979,6 +979,21 @@ int launch_sim3_ransac(gsf_ctx* ctx, const double* src, const double* dst, const
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
+// K3 (ref :428-459); bad_quat (may be NULL): OR of "a quaternion could not be normalised" per trajectory -- zeroed here unless the caller's
+// chain has done so already (the whole-run chain: one fill launch fewer)
+int launch_apply_sim3(gsf_ctx* ctx, const double* pos, const double* quat, const int64_t* offsets, int64_t B, const double* R, const double* t,
+                      const double* s, double* pos_out, double* quat_out, int32_t* bad_quat, bool bad_quat_zeroed)
+{
+    if (bad_quat && !bad_quat_zeroed) GSF_HIP(hipMemsetAsync(bad_quat, 0, (size_t)B * 4, ctx->stream));
+    // few trajectories -> several blocks per trajectory so a single long track still fills the chip
+    const unsigned gy = B >= 2048 ? 1u : (B >= 256 ? 4u : 64u);
+    if (ctx->ekf_variant == 11)                                              // A/B: the per-pose accesses of rounds 1-2
+        hipLaunchKernelGGL(apply_sim3_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
+    else
+        hipLaunchKernelGGL(apply_sim3_slab_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
+    GSF_HIP(hipGetLastError());
+    return GSF_OK;
+}
 }  // namespace gsf
 
 extern "C" {
@@ -1071,15 +1086,7 @@ int gsf_apply_sim3_batch_dev(gsf_ctx* ctx, const double* pos, const double* quat
     GSF_REQUIRE(B >= 0 && B <= 0x7fffffff, "bad B");
     if (B == 0) return GSF_OK;
     GSF_HIP(hipSetDevice(ctx->device));
-    if (bad_quat) GSF_HIP(hipMemsetAsync(bad_quat, 0, (size_t)B * 4, ctx->stream));
-    // few trajectories -> several blocks per trajectory so a single long track still fills the chip
-    const unsigned gy = B >= 2048 ? 1u : (B >= 256 ? 4u : 64u);
-    if (ctx->ekf_variant == 11)                                              // A/B: the per-pose accesses of rounds 1-2
-        hipLaunchKernelGGL(apply_sim3_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
-    else
-        hipLaunchKernelGGL(apply_sim3_slab_kernel, dim3((unsigned)B, gy), dim3(256), 0, ctx->stream, pos, quat, offsets, R, t, s, pos_out, quat_out, bad_quat);
-    GSF_HIP(hipGetLastError());
-    return GSF_OK;
+    return launch_apply_sim3(ctx, pos, quat, offsets, B, R, t, s, pos_out, quat_out, bad_quat, false);
 }
 
 }  // extern "C"
