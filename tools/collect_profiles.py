@@ -18,7 +18,7 @@ if os.path.exists(raw + "/bench_default.json"):
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_hash: the profile is only quoted by bench.py while the kernels are the ones it measured)
 traffic = {"kernel_source_hash": bench.kernel_source_hash()}
-pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_big_kernel<[\w, ]+>|ekf_wave_duo_kernel<[\w, ]+>|ekf_block_kernel<[\w, ]+>|windows_fused_kernel|windows_moments_kernel|windows_finalize_kernel|sim3_rows_kernel|fuse_pipeline_kernel<[\w, ]+>|ekf_fuse_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
+pat = re.compile(r"(ekf_wave_kernel<[\w, ]+>|ekf_wave_big_kernel<[\w, ]+>|ekf_wave_duo_kernel<[\w, ]+>|ekf_block_kernel<[\w, ]+>|windows_fused_kernel|windows_moments_kernel|windows_finalize_kernel|sim3_rows_kernel<\w+>|sim3_rows_kernel|fuse_pipeline_kernel<[\w, ]+>|ekf_fuse_kernel<[\w, ]+>|fuse_pipeline_kernel|ekf_fuse_kernel|umeyama_batch_kernel|ransac_batch_kernel|"
                  r"apply_sim3_kernel|apply_sim3_slab_kernel|utm_kernel<\w+>|gps_rows_to_utm_kernel|enu_kernel|time_align_kernel|eval_errors_kernel|eval_errors_lds_kernel|ransac_poly_kernel|mt_choice_kernel|"
                  r"ransac_rows_kernel|ransac_scan_kernel|ransac_finish_kernel|mt_tape_kernel|mt_transition_kernel|mt_compose_kernel|mt_expand_kernel|mt_resolve_kernel|mt_tape_trace_kernel|"
                  r"compact_valid_kernel|transpose_kernel<[\w, ]+>|robust_probe_kernel|gps_prefilter_chain_kernel|run_compact_rows_kernel|run_filtered_rows_kernel|run_outcome_kernel|"

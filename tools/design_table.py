@@ -24,7 +24,7 @@ ROWS = [
     ("bench_default", "fuse_pipeline_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, fused pipeline", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "ekf_fuse_kernel<1, 2, 2>", 100032, "C3 time-major, lane per trajectory, K4 only", 100_000_000, 100_000_000 * 145, "poses"),
     ("bench_default", "windows_fused_kernel", 1000064, "C4 1 M windows x 50 pairs (Umeyama)", 1_000_000, 1_000_000 * 2504, "windows"),
-    ("bench_default", "sim3_rows_kernel", 64000, "row choice (ref :973-998) + compaction of the chosen rows: first stage of the robust chain, 1 000 x 271", 271_000, None, "rows"),
+    ("bench_default", "sim3_rows_kernel<true>", 64000, "row choice (ref :973-998) + compaction of the chosen rows, from a register tile: first stage of the robust chain, 1 000 x 271", 271_000, None, "rows"),
     ("bench_default", "robust_probe_kernel", 64000, "early-exit probe of the robust chain, 1 000 x 271: draws + scores its own trials until one counts every row (ref :413), then the final fit", 1000, None, "trajectories"),
     ("bench_default", "gps_prefilter_chain_kernel", 64000, "GPS pre-filter of 1 000 logs (whole-run chain), windows walked on the device", 261_564, None, "fixes"),
     ("bench_default", "eval_errors_lds_kernel", 768000, "error metric of raw SLAM / Sim3 / EKF in one launch (whole-run chain), 1 000 x 271", 813_000, None, "poses"),
