@@ -104,14 +104,22 @@ for r in range(rounds):
             tot["rank_deficient_fit"] += 1
             continue
         dp, dq = float(np.abs(p[b] - o["pos"]).max()), float(np.abs(q[b] - o["quat"]).max())
-        if not (dp < 1e-6 and dq < 1e-8 and (status[b] & 0xff) == o["st"]):
+        # The orientation gate follows the conditioning of the FINAL fit (ref :420-421, on the inliers): a cross-covariance with singular values
+        # s1 >> s2 ~ s3 (a handful of inliers almost on one line) turns by |dH| / (s2 + s3) under a change dH of its entries, and the aligned fixes
+        # of the two sides differ by ~2e-9 m (the spline).  gpurun_out/stress_run_chain/fail_r25_b24.npz: 15 inliers, s = (1013, 0.048, 0.045),
+        # |dR| 3.2e-8, dq 1.5e-8, positions 4e-8 m -- NumPy's SVD-based Umeyama on the device's aligned rows returns the device's R to 6e-13 and on the
+        # oracle's rows the oracle's R to 5e-13.  Gate: 1e-8 up to s1 / (s2 + s3) = 1e3, proportional beyond.
+        mi = res.inlier_mask[b].cpu().numpy().astype(bool)
+        svi = np.linalg.svd((pos[b][mi] - pos[b][mi].mean(0)).T @ (o["aligned"][mi] - o["aligned"][mi].mean(0)), compute_uv=False) if mi.sum() >= 3 else np.ones(3)
+        q_gate = 1e-8 * max(1.0, svi[0] / max(svi[1] + svi[2], 1e-300) / 1e3)
+        if not (dp < 1e-6 and dq < q_gate and (status[b] & 0xff) == o["st"]):
             import json
             os.makedirs(os.path.join(ROOT, "gpurun_out", "stress_run_chain"), exist_ok=True)
             np.savez(os.path.join(ROOT, "gpurun_out", "stress_run_chain", f"fail_r{r}_b{b}.npz"), ts=ts[b], pos=pos[b], quat=quat[b], log=logs[b], seed=int(seeds[b]),
                      cfg=json.dumps(cfg), dev_R=res.R[b].cpu().numpy(), dev_t=res.t[b].cpu().numpy(), dev_s=float(res.s[b]), dev_mask=res.inlier_mask[b].cpu().numpy(),
                      dev_pos=p[b], dev_aligned=res.aligned[b].cpu().numpy(), dev_valid=va[b], orc_R=o["R"], orc_t=o["t"], orc_s=o["s"], orc_pos=o["pos"],
                      orc_aligned=o["aligned"], dev_info=res.trial_info[b].cpu().numpy())
-        assert dp < 1e-6 and dq < 1e-8 and (status[b] & 0xff) == o["st"], ("poses", ctx_, dp, dq, "R", float(np.abs(res.R[b].cpu().numpy().reshape(3, 3) - o["R"]).max()),
+        assert dp < 1e-6 and dq < q_gate and (status[b] & 0xff) == o["st"], ("poses", ctx_, dp, dq, q_gate, "R", float(np.abs(res.R[b].cpu().numpy().reshape(3, 3) - o["R"]).max()),
                                                                              "s", float(res.s[b]), o["s"], "n_inliers", o["n_inliers"])
         worst_p, worst_q = max(worst_p, dp), max(worst_q, dq)
         for row in range(3):
