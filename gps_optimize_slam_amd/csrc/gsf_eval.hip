@@ -11,6 +11,12 @@ namespace {
 
 constexpr int EVAL_THREADS = 256;
 
+// squared distance of a pose to a fix, the three products in ONE fixed association (explicit fma: the brute-force kernels and the pruned search
+// below must form the same bits whatever the compiler would contract).  Two facts the pruned search leans on: the result is >= fl(d_a * d_a)
+// for each axis a (non-negative terms added under a monotone rounding).
+__device__ __forceinline__ double pair_d2(const double dx, const double dy, const double dz) { return fma(dz, dz, fma(dy, dy, dx * dx)); }
+
+
 __device__ __forceinline__ double block_reduce_sum(double v, double* sh, int tid)
 {
     v = wave_sum(v);
@@ -44,8 +50,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_kernel(const double*
             // the candidate rows are wave-uniform scalar loads: branch-free and unrolled so that several are in flight at once
 #pragma unroll 8
             for (int64_t j = 0; j < N; ++j) {                            // :1030-1031
-                const double dx = x - g[j * 3], dy = y - g[j * 3 + 1], dz = z - g[j * 3 + 2];
-                const double d2 = dx * dx + dy * dy + dz * dz;
+                const double d2 = pair_d2(x - g[j * 3], y - g[j * 3 + 1], z - g[j * 3 + 2]);
                 best = fmin(best, in_set(j) ? d2 : INFINITY);
             }
             err = sqrt(best);
@@ -124,8 +129,7 @@ __device__ __forceinline__ void eval_nearest(const double* __restrict__ p, const
         const double gx = cx[k], gy = cy[k], gz = cz[k];
 #pragma unroll
         for (int u = 0; u < TQ; ++u) {
-            const double dx = qx[u] - gx, dy = qy[u] - gy, dz = qz[u] - gz;
-            best[u] = fmin(best[u], dx * dx + dy * dy + dz * dz);
+            best[u] = fmin(best[u], pair_d2(qx[u] - gx, qy[u] - gy, qz[u] - gz));
         }
     }
 #pragma unroll
@@ -165,6 +169,110 @@ __device__ __forceinline__ void eval_median(const double* cerr, const int M, con
     }
 }
 
+// ---- long tracks: the nearest fix by an exact pruned search instead of all M x M pairs (round 5: at 1 000 poses the metric cost ten times the
+// fusion it grades: 3.5 ms per 10 000 tracks).  The fixes are sorted along the axis of their largest extent; a query starts at its place in
+// that order and walks outwards on both sides, always to the side with the smaller axis gap, until that gap squared is no smaller than the best
+// squared distance so far: pair_d2 >= fl(gap^2) for every fix further out on that side, so none of them can lower the minimum -- the minimum is
+// the brute-force one, formed from the same pair_d2 bits.  A track that runs along its long axis examines a handful of fixes per pose; one
+// that does not (a vertical shaft) degrades towards all pairs, still exact.  The median's order statistics come from a bitonic sort of the
+// errors (M (log2 P)^2 / 4 compare-exchanges instead of M^2 compares); an error that is NaN makes the median NaN, as np.median does.
+constexpr int EVAL_PRUNE_MIN_M = 400;                                     // up to here the all-pairs tile is faster (36 dependent sorting steps cost more)
+constexpr int EVAL_PRUNE_QMAX = 6;                                        // queries per thread: EVAL_LDS_MAX_N / EVAL_THREADS
+template <bool WITH_IDX>
+__device__ __forceinline__ void eval_bitonic(double* a, uint16_t* ix, const int P, const int tid)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P / 2; t += EVAL_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;   // the pair (i, i ^ j), bit j of i clear
+                const double x = a[i], y = a[l];
+                if (((i & k) == 0) ? (x > y) : (x < y)) {
+                    a[i] = y; a[l] = x;
+                    if (WITH_IDX) { const uint16_t u = ix[i]; ix[i] = ix[l]; ix[l] = u; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__device__ __forceinline__ void eval_pruned(const double* __restrict__ p, const double* cx, const double* cy, const double* cz, double* skey,
+                                            const int32_t* qidx, uint16_t* sidx, double* __restrict__ e, const int M, const int tid, double* sh,
+                                            double* sh_med, double* __restrict__ stats_b)
+{
+    __shared__ double sh_ext[EVAL_THREADS / 64][6];
+    const int lane = tid & 63, wave = tid >> 6;
+    int P = 1;
+    while (P < M) P <<= 1;
+    // the axis of the largest extent
+    double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = tid; i < M; i += EVAL_THREADS) {
+        lo[0] = fmin(lo[0], cx[i]); hi[0] = fmax(hi[0], cx[i]); lo[1] = fmin(lo[1], cy[i]); hi[1] = fmax(hi[1], cy[i]);
+        lo[2] = fmin(lo[2], cz[i]); hi[2] = fmax(hi[2], cz[i]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 1; o < 64; o <<= 1) { lo[c] = fmin(lo[c], __shfl_xor(lo[c], o, 64)); hi[c] = fmax(hi[c], __shfl_xor(hi[c], o, 64)); }
+    if (lane == 0) { for (int c = 0; c < 3; ++c) { sh_ext[wave][c] = lo[c]; sh_ext[wave][3 + c] = hi[c]; } }
+    __syncthreads();
+    double ext[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double l = sh_ext[0][c], h = sh_ext[0][3 + c];
+        for (int w = 1; w < EVAL_THREADS / 64; ++w) { l = fmin(l, sh_ext[w][c]); h = fmax(h, sh_ext[w][3 + c]); }
+        ext[c] = h - l;
+    }
+    const int axis = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);   // block-uniform
+    const double* ca = axis == 0 ? cx : (axis == 1 ? cy : cz);
+    for (int i = tid; i < P; i += EVAL_THREADS) { skey[i] = i < M ? ca[i] : INFINITY; sidx[i] = (uint16_t)(i < M ? i : 0); }
+    __syncthreads();
+    eval_bitonic<true>(skey, sidx, P, tid);
+    // the queries: thread tid takes q = tid, tid + 256, ...
+    double err_r[EVAL_PRUNE_QMAX];
+    double cnt = 0.0, sum = 0.0, sum2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < EVAL_PRUNE_QMAX; ++u) {
+        const int q = tid + u * EVAL_THREADS;
+        err_r[u] = INFINITY;
+        if (q < M) {
+            const int row = qidx[q];
+            const double x = p[(int64_t)row * 3], y = p[(int64_t)row * 3 + 1], z = p[(int64_t)row * 3 + 2];
+            const double qa = axis == 0 ? x : (axis == 1 ? y : z);
+            int a = 0, c = M;                                             // first sorted fix with key >= qa
+            while (a < c) { const int m = (a + c) >> 1; if (skey[m] < qa) a = m + 1; else c = m; }
+            int l = a - 1, r = a;
+            double best = INFINITY;
+            for (;;) {
+                const double dl = l >= 0 ? qa - skey[l] : INFINITY, dr = r < M ? skey[r] - qa : INFINITY;
+                const bool left = dl <= dr;
+                const double gap = left ? dl : dr;
+                if (!(gap * gap < best)) break;                           // also ends when both sides are used up (inf) or the keys are NaN
+                const int j = sidx[left ? l : r];
+                best = fmin(best, pair_d2(x - cx[j], y - cy[j], z - cz[j]));
+                if (left) --l; else ++r;
+            }
+            const double err = sqrt(best);
+            err_r[u] = err; e[row] = err;
+            cnt += 1.0; sum += err; sum2 += err * err;
+        }
+    }
+    const double Mf = block_reduce_sum(cnt, sh, tid);
+    const double S1 = block_reduce_sum(sum, sh, tid);
+    const double S2 = block_reduce_sum(sum2, sh, tid);
+    __syncthreads();                                                     // every search has finished with the keys
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < EVAL_PRUNE_QMAX; ++u) { const int q = tid + u * EVAL_THREADS; if (q < P) { skey[q] = err_r[u]; bad = bad || isnan(err_r[u]); } }
+    for (int q = tid + EVAL_PRUNE_QMAX * EVAL_THREADS; q < P; q += EVAL_THREADS) skey[q] = INFINITY;
+    const bool any_nan = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (!any_nan) eval_bitonic<false>(skey, sidx, P, tid);
+    if (tid == 0) {
+        stats_b[0] = Mf;
+        stats_b[1] = S1 / Mf;
+        stats_b[2] = any_nan ? NAN : 0.5 * (skey[(M - 1) / 2] + skey[M / 2]);
+        stats_b[3] = sqrt(S2 / Mf);
+    }
+}
+
 // The same metric for tracks of up to EVAL_LDS_MAX_N poses (every BASELINE config): the candidate set is compacted into LDS once
 // (coordinates, original index, later the errors), and the M x M pair work -- nearest fix, then the rank count of the median -- is
 // spread evenly: S adjacent lanes share a query (S = a power of two with M*S ~ 2 000 work items for the 256 threads), each walking
@@ -196,8 +304,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
     const double* t = ts + b * N; const double* p = traj + b * N * 3; const double* g = gps + b * N * 3;
     const uint8_t* v = valid + b * N;
     double* e = errors + b * N;
+    // long tracks (n > EVAL_PRUNE_MIN_M): the error array doubles as the sort buffer of P = next power of two >= n doubles, and a uint16 index
+    // array of P entries follows qidx (pruned search below); else cx[n], cy[n], cz[n], err[n], int32 qidx[n]
+    const bool long_layout = n > EVAL_PRUNE_MIN_M;
+    int Pn = 1;
+    while (Pn < n) Pn <<= 1;
     double* cx = dynl; double* cy = cx + n; double* cz = cy + n; double* cerr = cz + n;
-    int32_t* qidx = (int32_t*)(cerr + n);
+    int32_t* qidx = (int32_t*)(cerr + (long_layout ? Pn : n));
+    uint16_t* sidx = (uint16_t*)(qidx + n);
 #ifdef GSF_EVAL_TIMING
     long long ev_t[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const long long ev_w0 = wall_clock64();                              // 100 MHz, common to the chip
@@ -227,6 +341,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
     }
     EV_T(1);
     const int M = base;                                                  // block-uniform
+    if (long_layout && M > EVAL_PRUNE_MIN_M) {
+        eval_pruned(p, cx, cy, cz, cerr, qidx, sidx, e, M, tid, sh, sh_med, stats + b * 4);
+        return;
+    }
     int S = 1;
     while (S < 64 && M * (S * 2) <= 2048) S *= 2;
     const int part = tid & (S - 1);
@@ -281,13 +399,21 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
 }  // namespace
 
 namespace gsf {
+// dynamic LDS of eval_errors_lds_kernel (its two layouts)
+static size_t eval_lds_bytes(int64_t N)
+{
+    if (N <= EVAL_PRUNE_MIN_M) return (size_t)N * 36;
+    size_t P = 1;
+    while ((int64_t)P < N) P <<= 1;
+    return (size_t)N * 28 + P * 10;
+}
 // step 6 for the three tracks main_process_gui prints (raw SLAM, Sim3, EKF; ref :1027) against the same aligned fixes: ONE launch for tracks
 // up to EVAL_LDS_MAX_N poses; stats[3][B][4], errors[3][B][N]
 int launch_eval_errors3(gsf_ctx* ctx, const double* ts, const double* traj0, const double* traj1, const double* traj2, const double* aligned_gps,
                         const uint8_t* valid, int64_t B, int64_t N, double skip_seconds, double* stats, double* errors)
 {
     if (N <= EVAL_LDS_MAX_N) {
-        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B, 3), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, EvalSets{ { traj0, traj1, traj2 } },
+        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B, 3), dim3(EVAL_THREADS), eval_lds_bytes(N), ctx->stream, ts, EvalSets{ { traj0, traj1, traj2 } },
                            aligned_gps, valid, N, skip_seconds, stats, errors);
         GSF_HIP(hipGetLastError());
         return GSF_OK;
@@ -312,7 +438,7 @@ int gsf_eval_errors_batch_dev(gsf_ctx* ctx, const double* ts, const double* traj
     GSF_REQUIRE(ts && traj_pos && aligned_gps && valid && stats && errors, "NULL array");
     GSF_HIP(hipSetDevice(ctx->device));
     if (N <= EVAL_LDS_MAX_N)
-        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), (size_t)N * 36, ctx->stream, ts, EvalSets{ { traj_pos, nullptr, nullptr } },
+        hipLaunchKernelGGL(eval_errors_lds_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), eval_lds_bytes(N), ctx->stream, ts, EvalSets{ { traj_pos, nullptr, nullptr } },
                            aligned_gps, valid, N, skip_seconds, stats, errors);
     else
         hipLaunchKernelGGL(eval_errors_kernel, dim3((unsigned)B), dim3(EVAL_THREADS), 0, ctx->stream, ts, traj_pos, aligned_gps, valid, N, skip_seconds, stats, errors);

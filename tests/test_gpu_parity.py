@@ -779,6 +779,40 @@ def test_error_metric_kernel_every_tile_shape(B, N):
     assert (err[3][np.isfinite(err[3])] == 5.0).all()
 
 
+@pytest.mark.parametrize("shape", ["line", "circle", "shaft", "stacked", "two_clusters", "walk"])
+def test_error_metric_pruned_search_is_the_all_pairs_minimum(B, shape):
+    """Tracks of more than 400 evaluated poses take the pruned nearest-fix search (fixes sorted along their longest axis, walk outwards from the
+    query's place until the axis gap alone exceeds the best distance).  It must return the all-pairs minimum (:1030-1031) on geometries that
+    prune well (a line), badly (a circle: no long axis; a vertical shaft: the long axis is z), not at all (every fix at the same place along
+    two axes; two far clusters with the queries of one nearest to fixes of the other), and on a 3-D random walk -- against NumPy's cdist-min of
+    the same rows; N = 1 000 and 1 536 (the largest track the LDS kernel takes)."""
+    import torch
+    for N in (1000, 1536):
+        rng = np.random.default_rng(N + len(shape))
+        nb = 6
+        ts = np.tile(np.arange(N) * 0.1, (nb, 1))
+        u = np.arange(N)
+        if shape == "line": g = np.stack([3.0 * u, 0.5 * u, 0 * u], axis=1)[None].repeat(nb, 0) + rng.normal(size=(nb, N, 3)) * 0.3
+        elif shape == "circle": g = np.stack([200 * np.cos(u * 2 * np.pi / N), 200 * np.sin(u * 2 * np.pi / N), 0 * u], axis=1)[None].repeat(nb, 0) + rng.normal(size=(nb, N, 3)) * 0.3
+        elif shape == "shaft": g = np.stack([0 * u, 0 * u, 2.0 * u], axis=1)[None].repeat(nb, 0) + rng.normal(size=(nb, N, 3)) * 0.3
+        elif shape == "stacked": g = np.stack([np.full(N, 5.0), np.full(N, -7.0), rng.permutation(N) * 0.01], axis=1)[None].repeat(nb, 0).copy()
+        elif shape == "two_clusters": g = np.where((u % 2 == 0)[None, :, None], 0.0, 5000.0) + rng.normal(size=(nb, N, 3))
+        else: g = np.cumsum(rng.normal(size=(nb, N, 3)), axis=1)
+        p = g + rng.normal(size=(nb, N, 3)) * (2.0 if shape != "two_clusters" else 1.0)
+        if shape == "two_clusters": p = np.roll(p, 1, axis=1)               # a pose sits in the OTHER cluster than the fix of its own row
+        valid = (rng.random((nb, N)) < 0.9).astype(np.uint8)
+        T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+        stats, err = B.eval_errors_batch(T(ts), T(p), T(g), T(valid, torch.uint8), 1.0)
+        stats, err = stats.cpu().numpy(), err.cpu().numpy()
+        for b in range(nb):
+            sel = (valid[b] != 0) & (ts[b] > ts[b, 0] + 1.0)
+            assert sel.sum() > 400 and stats[b, 0] == sel.sum()
+            d = np.sqrt(((p[b][sel][:, None, :] - g[b][sel][None, :, :]) ** 2).sum(axis=2)).min(axis=1)
+            np.testing.assert_allclose(err[b][sel], d, atol=1e-9, rtol=1e-12)
+            np.testing.assert_allclose(stats[b, 1:], [d.mean(), np.median(d), np.sqrt((d ** 2).mean())], atol=1e-9, rtol=1e-12)
+            assert stats[b, 2] == np.median(err[b][sel])
+
+
 def test_run_fusion_headless_driver(E, golden, tmp_path):
     """Steps 1-7 of main_process_gui without the GUI, file in / file out, on a copy of the bundled-shaped data."""
     g, k = golden("c1_combined.npz"), golden("kat_bundled.npz")

@@ -89,6 +89,16 @@ try:
     out["next4_eval_errors_1000traj_271"] = {"ms": ms_e, "Mpairs_s": 1000 * 271 * 271 / ms_e / 1e3}
 except Exception as ex:                                                  # signature differences must not hide the other timings
     out["next4_eval_errors_1000traj_271"] = {"error": str(ex)}
+# ---- the same metric at the C3 track length (10 000 x 1 000): more than 400 evaluated poses -> the pruned nearest-fix search + sorted median
+del bt, fo
+try:
+    bl = B.TrajectoryBatch.synthetic(10000, 1000, layout=B.LAYOUT_TRAJ_MAJOR, seed=1)
+    fl = B.ekf_fuse_batch(bl)
+    ms_l = timed(lambda: B.eval_errors_batch(bl.ts, fl.pos, bl.gps, bl.valid, 5.0), reps=5)
+    out["next4_eval_errors_10000traj_1000"] = {"ms": ms_l, "poses_per_s": 1e7 / ms_l * 1e3}
+    del bl, fl
+except Exception as ex:
+    out["next4_eval_errors_10000traj_1000"] = {"error": str(ex)}
 # ---- the reference's draws on the device: 1 000 streams x 1 000 trials of permutation(271)[:4]
 st = B.mt19937_seed(np.arange(1000))
 ms_c = timed(lambda: B.mt19937_choice_batch(st, [271] * 1000, 1000, 4), reps=3)

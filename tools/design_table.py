@@ -50,6 +50,7 @@ ROWS = [
     ("aux", "time_align_kernel", 64000, "time alignment 1 000 x (271 stamps, 279 fixes)", 271_000, None, "stamps"),
     ("aux", "ransac_poly_kernel<128>", 3840000, "GPS pre-filter problems: 30 000 x (150 rows, 50 trials of 6)", 30000, None, "problems"),
     ("aux", "eval_errors_lds_kernel", 256000, "error metric, 1 000 x 271", 271_000, None, "poses"),
+    ("aux", "eval_errors_lds_kernel", 2560000, "error metric at the C3 track length, 10 000 x 1 000 (pruned nearest-fix search, sorted median)", 10_000_000, None, "poses"),
 ]
 
 
