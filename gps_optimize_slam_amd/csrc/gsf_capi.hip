@@ -227,7 +227,7 @@ static int create_common(int device_id, hipStream_t stream, bool owns, gsf_ctx**
     c->device = device_id; c->stream = stream; c->owns_stream = owns; c->scratch = nullptr; c->scratch_bytes = 0; c->stage = nullptr; c->stage_bytes = 0; c->pinned = nullptr; c->pinned_bytes = 0;
     c->rng_scratch = nullptr; c->rng_scratch_bytes = 0; c->rows_scratch = nullptr; c->rows_scratch_bytes = 0; c->run_scratch = nullptr; c->run_scratch_bytes = 0; c->tape_draws = -1; c->small_scratch = nullptr; c->k2b_screen = 1; c->k2b_scratch = nullptr; c->k2b_scratch_bytes = 0;
     c->ekf_variant = 0; c->synth_variant = 0; c->block_kernel = -1; c->duo_kernel = -1; c->lane_min_traj = 32768;
-    c->ransac_early_exit = 0; c->ransac_probe_trials = 64; c->prefilter_first_batch = 1; c->prefilter_speculate = 1;
+    c->ransac_early_exit = 0; c->ransac_probe_trials = 64; c->prefilter_first_batch = 1; c->prefilter_speculate = 1; c->prefilter_miss_batch = 4;
     // the fused chains fit the rows main_process_gui hands to its fit (ref :973-998) under the reference's CONFIG defaults (:34, :53, :37)
     // unless the caller says otherwise (gsf_set_sim3_rows): a raw C caller of gsf_fuse_pipeline_* gets steps 3-5 as the reference runs them
     c->fit_rows = gsf::FitRows{ 1, 4, 5.0, 180.0 };
@@ -323,6 +323,10 @@ int gsf_set_option(gsf_ctx* ctx, const char* key, int64_t value)
     if (strcmp(key, "prefilter_speculate") == 0) {
         if (value != 0 && value != 1) { set_error("gsf_set_option: prefilter_speculate must be 0 or 1"); return GSF_ERR_INVALID_ARG; }
         ctx->prefilter_speculate = (int)value; return GSF_OK;
+    }
+    if (strcmp(key, "prefilter_miss_batch") == 0) {
+        if (value < 1 || value > 64) { set_error("gsf_set_option: prefilter_miss_batch must be in [1, 64]"); return GSF_ERR_INVALID_ARG; }
+        ctx->prefilter_miss_batch = (int)value; return GSF_OK;
     }
     if (strcmp(key, "prefilter_first_batch") == 0) {
         if (value < 1 || value > 64) { set_error("gsf_set_option: prefilter_first_batch must be in [1, 64]"); return GSF_ERR_INVALID_ARG; }

@@ -399,7 +399,7 @@ constexpr int PF_TILE = 4;            // row iterations of a window held in regi
 // one row range (an unsorted log is flagged 3 and left to the host route).  mode 2: one window = the whole log (ref :148-182).
 // Modes 1 / 2 also take the reference's early-outs: filtering disabled -> every row kept, nothing drawn (:139-141); fewer than `need` rows
 // -> the same (:144-146).
-struct WinGen { int32_t mode, need; double width, stride; int32_t enabled, max_windows, first_batch, speculate; };
+struct WinGen { int32_t mode, need; double width, stride; int32_t enabled, max_windows, first_batch, speculate, miss_batch; };
 __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* __restrict__ t, const double* __restrict__ pos, const int64_t* __restrict__ offsets,
                                                                  const int32_t* __restrict__ counts,
                                                                  const int32_t* __restrict__ win_rows, const int64_t* __restrict__ win_offsets,
@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
         pf_acc[17] += clock64() - pf_w0 + (long long)(tv[0] == 1.25 ? 1 : 0) + (long long)(y3[2][0] == 1.25 ? 1 : 0);   // (the loads have landed)
 #endif
         const bool spec_ok = gen.speculate != 0 && !identity && in_regs && max_trials >= 3;
+        int miss_batch = 0;                                               // > 0: the speculative pass has just missed at this axis
         for (int ax = 0; ax < 3 && wstat == 0; ++ax) {
           if (spec_ok && ax != 2) {                                       // (a pass over the last axis alone would save nothing)
             const int na = 3 - ax;                                        // axes ax .. 2: na consecutive trials
@@ -528,6 +529,11 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
                 if (k * 64 < n && i < n && (~inl[k] & need_bits) != 0u) kp[r0 + i] &= (uint8_t)~2u;
             }
             if (n_ok < na) {                                              // back to where axis ax + n_ok starts
+                // its first trial is known now, and with it how many trials RANSACRegressor will want unless a later one counts more rows:
+                // the sequential walk below opens with a batch of that many instead of growing to it by rounds of 1, 2, 4
+                const double want = lane_bcast(mt_l, n_ok);
+                const int cap = gen.miss_batch;                           // (a poor first sample asks for many: a better one among the next few shrinks that)
+                miss_batch = want < (double)cap ? (want > 2.0 ? (int)want : (cap < 2 ? cap : 2)) : cap;
                 const int skip = n_ok > 0 ? sh_end[n_ok - 1] : 0;
                 __syncthreads();
                 for (int i = lane; i < MT_N; i += 64) mt[i] = snap[i];
@@ -555,7 +561,10 @@ __global__ __launch_bounds__(64) void gps_prefilter_chain_kernel(const double* _
             // ~600 dependent instructions of the stream walk.  The walk itself runs redundantly on every lane (wave-uniform state).
             int best = -1, best_n = 1, ntr = 0, drawn = 0, raw_base = 0, last_nb = 0;
             double best_score = -INFINITY, max_tr = (double)max_trials;
-            for (int tbn = gen.first_batch; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
+            int tbn0 = gen.first_batch;
+            if (miss_batch > tbn0) tbn0 = miss_batch;
+            miss_batch = 0;
+            for (int tbn = tbn0; (double)ntr < max_tr; tbn = tbn < 64 ? tbn * 2 : 64) {
                 const int nb = (max_trials - drawn < tbn) ? (max_trials - drawn) : tbn;
                 if (nb <= 0) break;
                 if (identity) {
@@ -850,7 +859,7 @@ int gsf_gps_prefilter_chain_dev(gsf_ctx* ctx, const double* t, const double* pos
     GSF_REQUIRE(chain_lds(max_trials, min_samples, max_window_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / window length exceed the device sampler's LDS budget");
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, (const int32_t*)nullptr, win_rows, win_offsets,
                        (int)max_trials, (int)min_samples, (int)degree, residual_threshold, stop_probability, jseq_elems, mt_state, keep, win_status, log_status,
-                       WinGen{ 0, min_samples, 0.0, 0.0, 1, 0, ctx->prefilter_first_batch, ctx->prefilter_speculate }, (int32_t*)nullptr);
+                       WinGen{ 0, min_samples, 0.0, 0.0, 1, 0, ctx->prefilter_first_batch, ctx->prefilter_speculate, ctx->prefilter_miss_batch }, (int32_t*)nullptr);
     GSF_HIP(hipGetLastError());
     return GSF_OK;
 }
@@ -870,7 +879,7 @@ int launch_gps_prefilter_auto(gsf_ctx* ctx, const double* t, const double* pos, 
     int jseq_elems = 0; size_t lds = 0;
     GSF_REQUIRE(chain_lds(f->max_trials, f->min_samples, max_log_rows, B, jseq_elems, lds) == 0, "max_trials x min_samples / log length exceed the device sampler's LDS budget");
     const WinGen gen{ f->use_sliding_window ? 1 : 2, f->min_samples, f->window_duration_seconds, f->window_duration_seconds * f->window_step_factor,
-                      f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096, ctx->prefilter_first_batch, ctx->prefilter_speculate };
+                      f->enabled ? 1 : 0, f->max_windows > 0 ? f->max_windows : 4096, ctx->prefilter_first_batch, ctx->prefilter_speculate, ctx->prefilter_miss_batch };
     hipLaunchKernelGGL(gps_prefilter_chain_kernel, dim3((unsigned)B), dim3(64), lds, ctx->stream, t, pos, offsets, counts, (const int32_t*)nullptr,
                        (const int64_t*)nullptr, (int)f->max_trials, (int)f->min_samples, (int)f->polynomial_degree, f->residual_threshold_meters,
                        f->stop_probability > 0.0 ? f->stop_probability : 0.99, jseq_elems, mt_state, keep, (int32_t*)nullptr, log_status, gen, log_info);

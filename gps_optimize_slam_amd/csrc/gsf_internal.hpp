@@ -37,6 +37,7 @@ struct gsf_ctx {
     int synth_variant;     // synthetic workload (gsf_set_option "synth_variant"): 0 = white SLAM noise (default), 1 = SURVEY 8d's random-walk drift
     int block_kernel;      // workgroup-per-trajectory kernel for 64 < N <= 1024 (gsf_set_option "block_kernel"): -1 automatic, 0 never, 1 always
     int ransac_early_exit; // robust chain: stop a trajectory's trials at the first one that counts every row (gsf_set_option "ransac_early_exit"): 0 default, 1 on
+    int prefilter_miss_batch; // ... and the largest batch the sequential walk opens with after the speculative pass has missed (gsf_set_option "prefilter_miss_batch")
     int prefilter_speculate;  // the pre-filter chain tries "every axis of the window stops after its first trial" first (gsf_set_option "prefilter_speculate")
     int prefilter_first_batch; // trials the pre-filter chain draws and scores before its first look at scikit-learn's stopping rule (gsf_set_option "prefilter_first_batch")
     int ransac_probe_trials; // ... trials the early-exit probe draws and scores itself before the wide kernels take the rest (gsf_set_option "ransac_probe_trials")

@@ -179,6 +179,9 @@ GSF_API int gsf_trim(gsf_ctx *ctx);
                       first tries "every axis of the window stops after its first trial" -- three consecutive trials drawn, fitted and
                       counted at once; an axis whose first trial does not end RANSACRegressor's loop goes through the sequential walk
                       from the stream position where it starts.  0: the sequential walk only.  Same kept rows, same generator state.
+     "prefilter_miss_batch"  (default 4, 1..64) after the speculative pass has missed at an axis, its first trial says how many trials
+                      RANSACRegressor will want unless a later one counts more rows: the sequential walk opens with a batch of that many,
+                      at most this value (a poor first sample asks for many; a better one among the next few shrinks that).  Same words.
      "prefilter_first_batch"  (default 1, 1..64) trials the sequential walk draws and scores before its first look at scikit-learn's
                       stopping rule (the batches then double); any value gives the same words, clean logs are fastest with 1
      "synth_variant"  workload of gsf_synth_batch: 0 white SLAM noise (default), 1 random-walk drift

@@ -111,15 +111,18 @@ for r in range(rounds):
         # oracle's rows the oracle's R to 5e-13.  Gate: 1e-8 up to s1 / (s2 + s3) = 1e3, proportional beyond.
         mi = res.inlier_mask[b].cpu().numpy().astype(bool)
         svi = np.linalg.svd((pos[b][mi] - pos[b][mi].mean(0)).T @ (o["aligned"][mi] - o["aligned"][mi].mean(0)), compute_uv=False) if mi.sum() >= 3 else np.ones(3)
-        q_gate = 1e-8 * max(1.0, svi[0] / max(svi[1] + svi[2], 1e-300) / 1e3)
-        if not (dp < 1e-6 and dq < q_gate and (status[b] & 0xff) == o["st"]):
+        amp = svi[0] / max(svi[1] + svi[2], 1e-300)
+        # (positions follow with the lever arm of the track: fail_r13_b35.npz -- 58 inliers on a straight stretch of a 940 m track, s1 / (s2 + s3) =
+        # 1.3e5, |dR| 3.6e-8 on both sides' own rows, poses 3.6e-6 m apart)
+        q_gate, p_gate = 1e-8 * max(1.0, amp / 1e3), 1e-6 * max(1.0, amp / 1e4)
+        if not (dp < p_gate and dq < q_gate and (status[b] & 0xff) == o["st"]):
             import json
             os.makedirs(os.path.join(ROOT, "gpurun_out", "stress_run_chain"), exist_ok=True)
             np.savez(os.path.join(ROOT, "gpurun_out", "stress_run_chain", f"fail_r{r}_b{b}.npz"), ts=ts[b], pos=pos[b], quat=quat[b], log=logs[b], seed=int(seeds[b]),
                      cfg=json.dumps(cfg), dev_R=res.R[b].cpu().numpy(), dev_t=res.t[b].cpu().numpy(), dev_s=float(res.s[b]), dev_mask=res.inlier_mask[b].cpu().numpy(),
                      dev_pos=p[b], dev_aligned=res.aligned[b].cpu().numpy(), dev_valid=va[b], orc_R=o["R"], orc_t=o["t"], orc_s=o["s"], orc_pos=o["pos"],
                      orc_aligned=o["aligned"], dev_info=res.trial_info[b].cpu().numpy())
-        assert dp < 1e-6 and dq < q_gate and (status[b] & 0xff) == o["st"], ("poses", ctx_, dp, dq, q_gate, "R", float(np.abs(res.R[b].cpu().numpy().reshape(3, 3) - o["R"]).max()),
+        assert dp < p_gate and dq < q_gate and (status[b] & 0xff) == o["st"], ("poses", ctx_, dp, dq, q_gate, p_gate, "R", float(np.abs(res.R[b].cpu().numpy().reshape(3, 3) - o["R"]).max()),
                                                                              "s", float(res.s[b]), o["s"], "n_inliers", o["n_inliers"])
         worst_p, worst_q = max(worst_p, dp), max(worst_q, dq)
         for row in range(3):
@@ -127,7 +130,7 @@ for r in range(rounds):
             assert int(stats[row, b, 0]) == e["count"], ("step-6 count", ctx_)
             if e["count"]:
                 d6 = float(np.abs(stats[row, b, 1:] - np.array([e["mean"], e["median"], e["rmse"]])).max()) if row else 0.0
-                assert d6 < 1e-6, ("step 6", ctx_, row, d6)
+                assert d6 < p_gate, ("step 6", ctx_, row, d6)
                 worst_s6 = max(worst_s6, d6)
         tot["ok"] += 1
     st_e = B.mt19937_seed(seeds)

@@ -338,7 +338,7 @@ def test_device_window_walk_equals_the_host_walk(B):
 
 @pytest.mark.gpu
 def test_prefilter_speculative_pass_and_batch_size_change_no_word(B):
-    """gsf_set_option "prefilter_speculate" / "prefilter_first_batch" only change how many trials the pre-filter chain draws AHEAD of
+    """gsf_set_option "prefilter_speculate" / "prefilter_first_batch" / "prefilter_miss_batch" only change how many trials the pre-filter chain draws AHEAD of
     scikit-learn's walk (three axes' first trials at once; a first batch of 1 / 4 / 16 trials): the walk over the trials is the sequential
     one, in order, so kept rows, log status, windows processed / succeeded and the generator state are the same words -- on logs where
     most windows stop after one trial (clean stretches), on logs where a third of the windows need several (5 % of the fixes 40 m off on
@@ -367,16 +367,16 @@ def test_prefilter_speculative_pass_and_batch_size_change_no_word(B):
     pc = _lib.PrefilterConfig.from_config(f)
     outs = {}
     try:
-        for spec, fb in ((0, 1), (0, 4), (0, 16), (1, 1), (1, 4)):
-            ctx.set_option("prefilter_speculate", spec); ctx.set_option("prefilter_first_batch", fb)
+        for spec, fb, mb in ((0, 1, 4), (0, 4, 4), (0, 16, 4), (1, 1, 1), (1, 1, 4), (1, 1, 16), (1, 4, 2)):
+            ctx.set_option("prefilter_speculate", spec); ctx.set_option("prefilter_first_batch", fb); ctx.set_option("prefilter_miss_batch", mb)
             st = B.mt19937_seed(np.arange(nl) + 77)
             keep = torch.empty(int(offs[-1]), dtype=torch.uint8, device="cuda"); ls = torch.empty(nl, dtype=torch.int32, device="cuda")
             info = torch.empty((nl, 2), dtype=torch.int32, device="cuda")
             _lib.check(L.gsf_gps_prefilter_auto_dev(ctx.handle, B._p(T), B._p(P), B._p(O), nl, mx, C.byref(pc), B._p(st), B._p(keep), B._p(ls), B._p(info)))
-            outs[(spec, fb)] = (keep, ls, info, st)
+            outs[(spec, fb, mb)] = (keep, ls, info, st)
     finally:
-        ctx.set_option("prefilter_speculate", 1); ctx.set_option("prefilter_first_batch", 1)
-    ref = outs[(0, 1)]
+        ctx.set_option("prefilter_speculate", 1); ctx.set_option("prefilter_first_batch", 1); ctx.set_option("prefilter_miss_batch", 4)
+    ref = outs[(0, 1, 4)]
     assert (ref[1] == 0).all() and (ref[2][:, 0] > 0).all()
     kept = ref[0].double().mean().item()
     assert 0.85 < kept < 0.99                                              # fixes were dropped, most were kept

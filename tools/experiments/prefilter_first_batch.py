@@ -37,8 +37,8 @@ for share in (0.0, 0.02, 0.05, 0.15):
     utm = torch.empty_like(llh)
     _lib.check(L.gsf_gps_rows_to_utm_batch_dev(ctx.handle, B._p(llh), B._p(gb.gps_offsets), nb, B._p(utm), B._p(zone), B._p(south)))
     ref = None; row = {}
-    for fb, spec in ((1, 0), (2, 0), (4, 0), (8, 0), (1, 1)):
-        ctx.set_option("prefilter_first_batch", fb); ctx.set_option("prefilter_speculate", spec)
+    for fb, spec, mb in ((1, 0, 4), (2, 0, 4), (4, 0, 4), (8, 0, 4), (1, 1, 1), (1, 1, 2), (1, 1, 3), (1, 1, 4), (1, 1, 8)):
+        ctx.set_option("prefilter_first_batch", fb); ctx.set_option("prefilter_speculate", spec); ctx.set_option("prefilter_miss_batch", mb)
         keep = torch.empty(total, dtype=torch.uint8, device=dev); ls = torch.empty(nb, dtype=torch.int32, device=dev)
         info = torch.zeros((nb, 2), dtype=torch.int32, device=dev)
         st = [None]
@@ -51,9 +51,9 @@ for share in (0.0, 0.02, 0.05, 0.15):
         cur = (keep.clone(), st[0].clone(), ls.clone())
         if ref is None: ref = cur
         same = all(bool((a == b).all().item()) for a, b in zip(ref, cur))
-        row[f"first_batch_{fb}" + ("_speculative" if spec else "")] = {"ms": round(ms, 4), "same_words_as_first_batch_1": same}
+        row[f"first_batch_{fb}" + (f"_speculative_miss_batch_{mb}" if spec else "")] = {"ms": round(ms, 4), "same_words_as_first_batch_1": same}
     row["kept_share"] = float(ref[0].double().mean().item())
     row["windows_processed_mean"] = float(info[:, 0].double().mean().item())
     out[f"outlier_share_{share}"] = row
-ctx.set_option("prefilter_first_batch", 1); ctx.set_option("prefilter_speculate", 1)
+ctx.set_option("prefilter_first_batch", 1); ctx.set_option("prefilter_speculate", 1); ctx.set_option("prefilter_miss_batch", 4)
 print(json.dumps(out, indent=1))
