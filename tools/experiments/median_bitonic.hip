@@ -83,6 +83,32 @@ __global__ __launch_bounds__(THREADS) void median_bitonic_kernel(const double* _
     if (tid == 0) out[blockIdx.x] = 0.5 * (a[(M - 1) / 2] + a[M / 2]);
 }
 
+// the same network, block barriers only around the steps whose pairs cross the 128-element slab a wave owns (j >= 128): comparator t works on
+// elements inside slab t / 64 while j <= 64, and one wave's LDS instructions complete in issue order -- the compiler is told not to move them
+__global__ __launch_bounds__(THREADS) void median_bitonic_wave_kernel(const double* __restrict__ err, int M, int P, double* __restrict__ out)
+{
+    extern __shared__ double a[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P; i += THREADS) a[i] = i < M ? err[(size_t)blockIdx.x * M + i] : INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P / 2; t += THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const double x = a[i], y = a[l];
+                const bool sw = up ? (x > y) : (x < y);
+                if (sw) { a[i] = y; a[l] = x; }
+            }
+            if (j >= 128 || (j == 1 && k >= 128)) __syncthreads();
+            else asm volatile("" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = 0.5 * (a[(M - 1) / 2] + a[M / 2]);
+}
+
 int main(int argc, char** argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 3000, M = argc > 2 ? atoi(argv[2]) : 220;
@@ -90,11 +116,11 @@ int main(int argc, char** argv)
     std::vector<double> h((size_t)B * M);
     srand(7);
     for (auto& v : h) v = (rand() % 100000) * 1e-4;                                  // ties included
-    double *d, *o1, *o2;
-    CK(hipMalloc(&d, h.size() * 8)); CK(hipMalloc(&o1, B * 8)); CK(hipMalloc(&o2, B * 8));
+    double *d, *o1, *o2, *o3;
+    CK(hipMalloc(&d, h.size() * 8)); CK(hipMalloc(&o1, B * 8)); CK(hipMalloc(&o2, B * 8)); CK(hipMalloc(&o3, B * 8));
     CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    float ms1 = 0, ms2 = 0;
+    float ms1 = 0, ms2 = 0, ms3 = 0;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(median_rank_kernel, dim3(B), dim3(THREADS), (size_t)M * 8, 0, d, M, o1);
@@ -102,17 +128,20 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e0));
         for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(median_bitonic_kernel, dim3(B), dim3(THREADS), (size_t)P * 8, 0, d, M, P, o2);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
+        CK(hipEventRecord(e0));
+        for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(median_bitonic_wave_kernel, dim3(B), dim3(THREADS), (size_t)P * 8, 0, d, M, P, o3);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms3, e0, e1));
     }
-    std::vector<double> r1(B), r2(B);
-    CK(hipMemcpy(r1.data(), o1, B * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), o2, B * 8, hipMemcpyDeviceToHost));
+    std::vector<double> r1(B), r2(B), r3(B);
+    CK(hipMemcpy(r1.data(), o1, B * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), o2, B * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(r3.data(), o3, B * 8, hipMemcpyDeviceToHost));
     int bad = 0;
     for (int b = 0; b < B; ++b) {
         std::vector<double> s(h.begin() + (size_t)b * M, h.begin() + (size_t)(b + 1) * M);
         std::sort(s.begin(), s.end());
         const double ref = 0.5 * (s[(M - 1) / 2] + s[M / 2]);
-        if (r1[b] != ref || r2[b] != ref) ++bad;
+        if (r1[b] != ref || r2[b] != ref || r3[b] != ref) ++bad;
     }
-    printf("B = %d blocks, M = %d errors (sorted array padded to %d): rank count %.1f us per launch, bitonic sort %.1f us per launch; medians wrong: %d\n",
-           B, M, P, ms1 / 20 * 1e3, ms2 / 20 * 1e3, bad);
+    printf("B = %d blocks, M = %d errors (sorted array padded to %d): rank count %.1f us per launch, bitonic sort %.1f us, with wave-local steps %.1f us; medians wrong: %d\n",
+           B, M, P, ms1 / 20 * 1e3, ms2 / 20 * 1e3, ms3 / 20 * 1e3, bad);
     return bad != 0;
 }
