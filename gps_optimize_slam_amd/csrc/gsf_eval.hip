@@ -195,7 +195,7 @@ __device__ __forceinline__ void eval_bitonic(double* a, uint16_t* ix, const int 
         }
     }
 }
-__device__ __forceinline__ void eval_pruned(const double* __restrict__ p, const double* cx, const double* cy, const double* cz, double* skey,
+__device__ __forceinline__ bool eval_pruned(const double* __restrict__ p, const double* cx, const double* cy, const double* cz, double* skey,
                                             const int32_t* qidx, uint16_t* sidx, double* __restrict__ e, const int M, const int tid, double* sh,
                                             double* sh_med, double* __restrict__ stats_b)
 {
@@ -222,6 +222,23 @@ __device__ __forceinline__ void eval_pruned(const double* __restrict__ p, const 
         ext[c] = h - l;
     }
     const int axis = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);   // block-uniform
+    // Is there anything to prune?  The walk stops when the axis gap reaches the best distance, and a gap never exceeds the fixes' extent along the
+    // axis while the pose lies inside it: a track that is FAR from its fixes -- the raw SLAM track of step 6 sits in another frame, millions of
+    // metres away -- would visit every fix from every pose, one at a time (9.7 ms per 10 000 x 1 000 against the all-pairs tile's 3).  Probe: the
+    // middle pose's nearest fix by the whole block; farther than twice the extent -> the caller takes the all-pairs tile (same minima either way).
+    {
+        const int row = qidx[M / 2];
+        const double x = p[(int64_t)row * 3], y = p[(int64_t)row * 3 + 1], z = p[(int64_t)row * 3 + 2];
+        double b0 = INFINITY;
+        for (int i = tid; i < M; i += EVAL_THREADS) b0 = fmin(b0, pair_d2(x - cx[i], y - cy[i], z - cz[i]));
+        for (int o = 1; o < 64; o <<= 1) b0 = fmin(b0, __shfl_xor(b0, o, 64));
+        __syncthreads();                                                 // sh_ext has been read by every thread
+        if (lane == 0) sh_ext[wave][0] = b0;
+        __syncthreads();
+        double best0 = sh_ext[0][0];
+        for (int w = 1; w < EVAL_THREADS / 64; ++w) best0 = fmin(best0, sh_ext[w][0]);
+        if (!(best0 <= 4.0 * ext[axis] * ext[axis])) return false;       // block-uniform (NaN poses: the tile treats them as before)
+    }
     const double* ca = axis == 0 ? cx : (axis == 1 ? cy : cz);
     for (int i = tid; i < P; i += EVAL_THREADS) { skey[i] = i < M ? ca[i] : INFINITY; sidx[i] = (uint16_t)(i < M ? i : 0); }
     __syncthreads();
@@ -271,6 +288,7 @@ __device__ __forceinline__ void eval_pruned(const double* __restrict__ p, const 
         stats_b[2] = any_nan ? NAN : 0.5 * (skey[(M - 1) / 2] + skey[M / 2]);
         stats_b[3] = sqrt(S2 / Mf);
     }
+    return true;
 }
 
 // The same metric for tracks of up to EVAL_LDS_MAX_N poses (every BASELINE config): the candidate set is compacted into LDS once
@@ -341,10 +359,9 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
     }
     EV_T(1);
     const int M = base;                                                  // block-uniform
-    if (long_layout && M > EVAL_PRUNE_MIN_M) {
-        eval_pruned(p, cx, cy, cz, cerr, qidx, sidx, e, M, tid, sh, sh_med, stats + b * 4);
-        return;
-    }
+    const bool long_track = long_layout && M > EVAL_PRUNE_MIN_M;           // block-uniform
+    if (long_track && eval_pruned(p, cx, cy, cz, cerr, qidx, sidx, e, M, tid, sh, sh_med, stats + b * 4)) return;
+    // (a long track far from its fixes comes back: all-pairs nearest fix below, then the sorted median)
     int S = 1;
     while (S < 64 && M * (S * 2) <= 2048) S *= 2;
     const int part = tid & (S - 1);
@@ -371,8 +388,19 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_errors_lds_kernel(const dou
     if (tid == 0) { sh_med[0] = NAN; sh_med[1] = NAN; }
     __syncthreads();                                                     // cerr[] complete
     EV_T(5);
-    // ---- np.median: the two middle order statistics by rank count (ties broken by row order), the same query tile
-    if (M > 0) {
+    // ---- np.median: the two middle order statistics -- long tracks: from a bitonic sort of the errors (the error array has P >= M slots there);
+    // else by rank count (ties broken by row order), the same query tile
+    if (long_track) {
+        int P = 1;
+        while (P < M) P <<= 1;
+        bool bad = false;
+        for (int i = tid; i < P; i += EVAL_THREADS) { if (i >= M) cerr[i] = INFINITY; else bad = bad || isnan(cerr[i]); }
+        const bool any_nan = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (!any_nan) {
+            eval_bitonic<false>(cerr, sidx, P, tid);
+            if (tid == 0) { sh_med[0] = cerr[(M - 1) / 2]; sh_med[1] = cerr[M / 2]; }
+        }
+    } else if (M > 0) {
         switch (passes) {
         case 0: case 1: eval_median<1>(cerr, M, S, part, q0, G, sh_med); break;
 #define GSF_EVAL_CASE(T) case T: eval_median<T>(cerr, M, S, part, q0, G, sh_med); break;

@@ -799,6 +799,7 @@ def test_error_metric_pruned_search_is_the_all_pairs_minimum(B, shape):
         elif shape == "two_clusters": g = np.where((u % 2 == 0)[None, :, None], 0.0, 5000.0) + rng.normal(size=(nb, N, 3))
         else: g = np.cumsum(rng.normal(size=(nb, N, 3)), axis=1)
         p = g + rng.normal(size=(nb, N, 3)) * (2.0 if shape != "two_clusters" else 1.0)
+        p[nb - 1] += np.array([4.0e5, 5.4e6, 100.0])                       # one track in another frame (step 6's raw SLAM row): the all-pairs fall-back + sorted median
         if shape == "two_clusters": p = np.roll(p, 1, axis=1)               # a pose sits in the OTHER cluster than the fix of its own row
         valid = (rng.random((nb, N)) < 0.9).astype(np.uint8)
         T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
@@ -808,8 +809,8 @@ def test_error_metric_pruned_search_is_the_all_pairs_minimum(B, shape):
             sel = (valid[b] != 0) & (ts[b] > ts[b, 0] + 1.0)
             assert sel.sum() > 400 and stats[b, 0] == sel.sum()
             d = np.sqrt(((p[b][sel][:, None, :] - g[b][sel][None, :, :]) ** 2).sum(axis=2)).min(axis=1)
-            np.testing.assert_allclose(err[b][sel], d, atol=1e-9, rtol=1e-12)
-            np.testing.assert_allclose(stats[b, 1:], [d.mean(), np.median(d), np.sqrt((d ** 2).mean())], atol=1e-9, rtol=1e-12)
+            np.testing.assert_allclose(err[b][sel], d, atol=2e-9, rtol=1e-12)
+            np.testing.assert_allclose(stats[b, 1:], [d.mean(), np.median(d), np.sqrt((d ** 2).mean())], atol=2e-9, rtol=1e-12)
             assert stats[b, 2] == np.median(err[b][sel])
 
 
